@@ -1,0 +1,231 @@
+/* libneurst_hip.so - C ABI of the MI355X (gfx950) kernels behind the neurst-ST
+ * TransformerTPE train/infer hot path.
+ *
+ * The reference (dqqcasia/neurst) has NO plugin / custom-op / FFI interface on this
+ * path: every op is a TensorFlow-1.15 library call made from Python.  Each entry point
+ * below therefore cites the reference Python function (file:line under the reference
+ * root) whose arithmetic it replaces; the Python classes in neurst_amd/st/ that keep
+ * the reference's names are the binding a maintainer swaps in.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative NEURST_E_* code; a thread-local
+ *    message is available from neurst_last_error();
+ *  - all pointers are DEVICE pointers owned by the caller (no allocation inside), all
+ *    calls are asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - tensors are dense row-major; `dtype` is NEURST_F32 or NEURST_BF16 for activations
+ *    (bf16 operands always accumulate in fp32); lengths / ids are int32 on device;
+ *  - dropout uses the counter hash of neurst_amd/csrc/common.h keyed by a 32-bit
+ *    call-site `key`; rate == 0 disables it.  Backward kernels regenerate the mask.
+ */
+#ifndef NEURST_HIP_H_
+#define NEURST_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { NEURST_F32 = 0, NEURST_BF16 = 1 };
+enum { NEURST_OK = 0, NEURST_E_INVALID = -1, NEURST_E_LAUNCH = -2, NEURST_E_UNSUPPORTED = -3 };
+enum { NEURST_MASK_NONE = 0, NEURST_MASK_KEYPAD = 1, NEURST_MASK_CAUSAL = 2 };
+
+const char* neurst_last_error(void);
+int neurst_abi_version(void);
+
+/* a1: splice(left=0,right=num_context) + down_sample(rate)
+ * st/tools/tftools/tfAudioTools.py:69-98, st/tools/tftools/tfRecord.py:827-845.
+ * x [B,Traw,F] fp32 -> out [B,ceil(Traw/rate),F*(num_context+1)] (out_dtype);
+ * len_out[b] = ceil(len_raw[b]/rate). Frames at or beyond len_raw[b] read as zero. */
+int neurst_splice_downsample(const float* x, const int32_t* len_raw, void* out, int32_t* len_out,
+                             int64_t B, int64_t Traw, int64_t F, int num_context, int rate,
+                             int out_dtype, void* stream);
+
+/* a3: SpecAugment, st/tools/tftools/tfAudioTools.py:134-212 (2 freq + 2 time masks).
+ * _params samples (f,f0,f',f0',t,t0,t',t0') per utterance with the build's hash RNG
+ * (TF's stream is not reproducible); _apply zeroes the bands in place. x [B,T,v] fp32. */
+int neurst_specaug_params(const float* x, int32_t* params, int64_t B, int64_t T, int64_t v,
+                          int F, int Tmax, float p, uint32_t key, void* stream);
+int neurst_specaug_apply(float* x, const int32_t* params, int64_t B, int64_t T, int64_t v, void* stream);
+
+/* a5 + dropout: y = dropout(x + signal[t,c]); st/layers/common_attention_v1.py:28-70,
+ * st/models/encoders/transformer_encoder.py:110-115. signal [T,C] fp32 (host-built table). */
+int neurst_add_timing_dropout_fwd(const void* x, int x_dtype, const float* signal, void* y, int y_dtype,
+                                  int64_t B, int64_t T, int64_t C, float rate, uint32_t key, void* stream);
+/* backward of any elementwise dropout: dx = dy * mask * 1/(1-rate) (flat index). */
+int neurst_dropout_bwd(const void* dy, void* dx, int64_t n, int dtype, float rate, uint32_t key, void* stream);
+
+/* a8/a9/a10/a16 GEMMs: C[M,N] = op(A)[M,K] . op(B)[K,N] (+bias[N]) (relu) (* (relu_src>0)) (+C)
+ * replaces `dense` (st/models/tools/utils.py:367-398), tf.layers.dense
+ * (transformer_encoder.py:117-122, fc_decoder.py:33-38, transformer_decoder.py:42-46)
+ * and their autodiff gradients.  trans_a: A stored [K,M]; trans_b: B stored [N,K].
+ * A,B have dtype `ab_dtype`; C has `c_dtype`; bias fp32; relu_src (dtype ab_dtype, ldc)
+ * gates the result by (relu_src > 0) (ReLU backward).  split_k > 1 requires fp32 C and
+ * accumulate (atomic adds into C). */
+int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bias, const void* relu_src,
+                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                         int trans_a, int trans_b, int ab_dtype, int c_dtype, int relu, int accumulate,
+                         int split_k, void* stream);
+/* column sums (bias gradients): out[n] (+)= sum_m x[m,n]; out fp32. */
+int neurst_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
+                  void* stream);
+
+/* a8: fused multi-head attention, st/models/tools/utils.py:545-553 +
+ * st/layers/common_attention_v1.py:180-204,244-266,325-365.  q [B,Tq,*], k/v [B,Tk,*]
+ * with row strides ldq/ldk/ldv (so packed qkv / kv projections are consumed in place),
+ * head h occupies columns [h*dh,(h+1)*dh).  softmax((q*dh^-0.5).k^T + bias) with the
+ * reference's additive -1e9 bias (KEYPAD: keys >= len_k[b]; CAUSAL: key > query),
+ * dropout on the weights, .v, heads merged into o [B,Tq,ldo].  lse [B,H,Tq] fp32 is
+ * saved for backward.  The [B,H,Tq,Tk] matrix is never materialised. */
+int neurst_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                   int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                   int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
+/* Same with explicit batch strides (elements) for q/k/v/o, used by the cached greedy decoder
+ * (a21) where K/V live in a [B,Lmax,2d] cache of which only the first Tk rows are valid. */
+int neurst_mha_fwd_strided(const void* q, const void* k, const void* v, void* o, float* lse,
+                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                           int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso,
+                           int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                           int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
+/* delta [B,H,Tq] fp32 workspace; dq/dk/dv written with strides lddq/lddk/lddv. */
+int neurst_mha_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                   const float* lse, float* delta, void* dq, void* dk, void* dv,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                   int64_t lddq, int64_t lddk, int64_t lddv,
+                   int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                   int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
+
+/* a7 (+a6): out = LN(x + dropout(y)) * (t < len[b]) ; st/models/tools/utils.py:324-337,
+ * st/layers/common_layers_v1.py:342-347 (eps 1e-6 inside rsqrt, biased variance).
+ * z = x + dropout(y) is written over y (in place) for backward; mean/rstd [rows] fp32.
+ * lens (may be NULL) zeroes rows t >= lens[b] (transformer_encoder.py:151), T = rows per b. */
+int neurst_dropout_add_layernorm_fwd(const void* x, void* y_inout_z, const float* gamma, const float* beta,
+                                     void* out, float* mean, float* rstd, int64_t rows, int64_t C,
+                                     float rate, uint32_t key, const int32_t* lens, int64_t T,
+                                     int dtype, void* stream);
+/* dz (gradient wrt x, and wrt y when rate==0) and dy = dz*mask*scale (dy may be NULL or == dz
+ * when rate == 0); dgamma/dbeta accumulate (+=) in fp32; partial [2*nblk*C] fp32 workspace
+ * where nblk = neurst_layernorm_bwd_blocks(rows). */
+int64_t neurst_layernorm_bwd_blocks(int64_t rows);
+int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z, const float* gamma,
+                                     const float* mean, const float* rstd, void* dz, void* dy,
+                                     float* dgamma, float* dbeta, float* partial,
+                                     int64_t rows, int64_t C, float rate, uint32_t key,
+                                     const int32_t* lens, int64_t T, int dtype, void* stream);
+
+/* gradient accumulation helper (a tensor consumed twice): dst += src, same dtype. */
+int neurst_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream);
+
+/* a4 lengths: out[b] = ceil(in[b] / div) (transformer_encoder.py:91-92). */
+int neurst_lens_ceil_div(const int32_t* in, int32_t* out, int64_t B, int div, void* stream);
+
+/* a6 standalone: x[b,t,:] *= (t < lens[b]) in place. */
+int neurst_mask_rows(void* x, const int32_t* lens, int64_t B, int64_t T, int64_t C, int dtype, void* stream);
+
+/* a15: decoder inputs, st/models/decoders/decoder.py:63-92 + tfTools.py:195-198 +
+ * TransformerTPE.py:335-338: inp[b,0]=sos, inp[b,l]=labels[b,l-1], zeroed at l >= len[b]. */
+int neurst_build_decoder_input(const int32_t* labels, const int32_t* len_labels, int32_t* inp,
+                               int64_t B, int64_t L, int32_t sos, void* stream);
+/* a16 embedding: out = dropout(2*table[ids] + signal[l]) (decoder.py:198-204,
+ * transformer_decoder.py:193-197); pos0 offsets the signal row (cached decoding). table fp32. */
+int neurst_embedding_fwd(const int32_t* ids, const float* table, const float* signal, void* out,
+                         int64_t B, int64_t L, int64_t D, int64_t V, float rate, uint32_t key,
+                         int out_dtype, void* stream);
+/* dtable[ids] += 2 * dropout_bwd(dout) (fp32 atomics; dtable pre-initialised by the caller). */
+int neurst_embedding_bwd(const int32_t* ids, const void* dout, float* dtable, int64_t B, int64_t L,
+                         int64_t D, int64_t V, float rate, uint32_t key, int dtype, void* stream);
+
+/* a11: tf.nn.ctc_loss(ctc_merge_repeated=True, ignore_longer_outputs_than_inputs=True,
+ * time_major=False) forward + gradient, call site st/models/TransformerTPE.py:74-104.
+ * logits [B,T,V] fp32 (blank = V-1, softmax internal). loss [B] fp32.  grad [B,T,V]
+ * (grad_dtype; may alias logits when fp32) = grad_scale * d loss_b / d logits.
+ * argmax [B,T] int32 (first maximum) is produced on the way (used by a12/a13).
+ * workspace: neurst_ctc_workspace_bytes(B,T,Umax). */
+int64_t neurst_ctc_workspace_bytes(int64_t B, int64_t T, int64_t Umax);
+int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_logits, const int32_t* labels,
+                            const int32_t* len_labels, float* loss, void* grad, int grad_dtype,
+                            int32_t* argmax, void* workspace, int64_t B, int64_t T, int64_t V,
+                            int64_t Umax, float grad_scale, void* stream);
+/* per-frame argmax only (inference path of a12/a13). */
+int neurst_argmax_rows(const float* logits, int32_t* argmax, int64_t rows, int64_t V, void* stream);
+/* a12: tf.nn.ctc_greedy_decoder(merge_repeated=True) + sparse_to_dense(default 0),
+ * TransformerTPE.py:106-125,251-259.  out [B,T] (zero padded), out_len [B]. */
+int neurst_ctc_greedy(const int32_t* argmax, const int32_t* len_logits, int32_t* out, int32_t* out_len,
+                      int64_t B, int64_t T, int32_t blank, void* stream);
+
+/* a13: shrink_layer, st/models/tools/blocks.py:8-38, in two steps so the host can size
+ * the output like the reference does (max(max count, 1)):
+ *  _index: keep frame t iff argmax != blank && argmax != argmax[t-1] && t < lens[b];
+ *          index [B,T] = source frame of the j-th kept frame (-1 beyond the count), new_len [B];
+ *  _fwd:   out [B,Tout,D] = gathered rows, zero padded (Tout <= T);
+ *  _bwd:   dx [B,T,D] = scatter of dout [B,Tout,D] (rows not kept get zero). */
+int neurst_shrink_index(const int32_t* argmax, const int32_t* lens, int32_t* index, int32_t* new_len,
+                        int64_t B, int64_t T, int32_t blank, void* stream);
+int neurst_shrink_fwd(const void* x, const int32_t* index, void* out, int64_t B, int64_t T, int64_t Tout,
+                      int64_t D, int dtype, void* stream);
+int neurst_shrink_bwd(const void* dout, const int32_t* index, void* dx, int64_t B, int64_t T, int64_t Tout,
+                      int64_t D, int dtype, void* stream);
+
+/* a17: smoothing_cross_entropy + mask + per-utterance mean, st/models/model_tools.py:17-38,
+ * st/models/seq2seqModel.py:157-191.  logits [B,L,V] fp32; xent [B,L] fp32 (masked, divided
+ * by len); loss_b = sum_l xent[b,l].  grad [B,L,V] (grad_dtype) = grad_scale * d loss_b/d logits. */
+int neurst_ls_xent_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* len_labels,
+                           float* xent, void* grad, int grad_dtype, int64_t B, int64_t L, int64_t V,
+                           float confidence, float grad_scale, void* stream);
+
+/* a18: tf.losses.mean_squared_error (st/models/kd_layer.py:9-11): partial sums of
+ * (pred-label)^2 into partial[nblk] (nblk = neurst_mse_blocks(n)); dpred = grad_scale*2*(pred-label)/n. */
+int64_t neurst_mse_blocks(int64_t n);
+int neurst_mse_fwd_bwd(const void* pred, const void* label, int label_dtype, float* partial, void* dpred,
+                       int64_t n, float grad_scale, int dtype, void* stream);
+
+/* a2 loss mix (TransformerTPE.py:385-418, :471): out[0]=mean_b(w_ctc*ctc_b + w_kd*mse + w_ast*ce_b),
+ * out[1]=mean ce_b, out[2]=mean ctc_b, out[3]=mse.  Any input may be NULL (treated as 0). */
+int neurst_loss_combine(const float* xent, const float* ctc, const float* mse_partial, int64_t n_partial,
+                        int64_t mse_numel, int64_t B, int64_t L, float w_ast, float w_ctc, float w_kd,
+                        float* out4, void* stream);
+
+/* a4: tf.layers.conv2d(SAME) -> layer_norm over channels -> ReLU
+ * (st/models/encoders/transformer_encoder.py:18-32,80-93) and the 3x3/1 SAME max-pool (:96-100).
+ * x [B,H,W,Cin] NHWC, w [kh,kw,Cin,Cout] fp32, out [B,Ho,Wo,Cout]; pre-LN conv output is
+ * kept in `conv_out` (same shape) for backward. */
+int neurst_conv2d_ln_relu_fwd(const void* x, const float* w, const float* bias, const float* gamma,
+                              const float* beta, void* conv_out, void* out, float* mean, float* rstd,
+                              int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                              int kh, int kw, int sh, int sw, int dtype, void* stream);
+/* dgamma/dbeta/dw/dbias accumulate (+=, fp32 atomics); dx may be NULL (first layer). */
+int neurst_conv2d_ln_relu_bwd(const void* dout, const void* x, const float* w, const float* gamma,
+                              const void* conv_out, const void* out, const float* mean, const float* rstd,
+                              void* dconv_ws, void* dx, float* dw, float* dbias, float* dgamma, float* dbeta,
+                              int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                              int kh, int kw, int sh, int sw, int dtype, void* stream);
+int neurst_maxpool3x3_fwd(const void* x, void* out, int8_t* argidx, int64_t B, int64_t H, int64_t W, int64_t C,
+                          int dtype, void* stream);
+int neurst_maxpool3x3_bwd(const void* dout, const int8_t* argidx, void* dx, int64_t B, int64_t H, int64_t W,
+                          int64_t C, int dtype, void* stream);
+
+/* a20: tf.train.AdamOptimizer(beta1=.9,beta2=.98,eps=1e-9) update on a flat arena
+ * (st/models/lstmModel.py:526-530): g is scaled by grad_scale first (1/world_size after a
+ * summed all-reduce, a19); lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.
+ * shadow (may be NULL) receives the bf16 copy of the updated parameters. */
+int neurst_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                     float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* dtype conversion fp32 -> bf16 (parameter shadow after loading weights). */
+int neurst_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int neurst_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+
+/* a21 helper: greedy step bookkeeping of decoder_with_caching
+ * (st/models/decoders/transformer_decoder.py:83-90): ids = argmax(logits[b,:]) (first max),
+ * preds[b,step] = ids, finished |= ids==eos, len_decoded += 1-finished, n_unfinished += !finished. */
+int neurst_greedy_step(const float* logits, int32_t* preds, int32_t* finished, int32_t* len_decoded,
+                       int32_t* n_unfinished, int64_t B, int64_t V, int64_t step, int64_t max_steps,
+                       int32_t eos, void* stream);
+
+/* kernel self-test: one 16x16xK MFMA tile product through the same fragment loaders the
+ * GEMM / attention kernels use (A [16,K], B^T [16,K] -> C [16,16] fp32). */
+int neurst_selftest_mma(const void* A, const void* Bt, float* C, int64_t K, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURST_HIP_H_ */

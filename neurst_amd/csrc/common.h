@@ -1,0 +1,140 @@
+// Shared device/host helpers for libneurst_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/neurst_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define NEURST_WAVE 64
+
+// ---- error plumbing --------------------------------------------------------
+void neurst_set_error(const char* fmt, ...);
+
+#define NEURST_CHECK_ARG(cond, ...)                  \
+  do {                                               \
+    if (!(cond)) {                                   \
+      neurst_set_error(__VA_ARGS__);                 \
+      return NEURST_E_INVALID;                       \
+    }                                                \
+  } while (0)
+
+#define NEURST_CHECK_LAUNCH(name)                                              \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      neurst_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return NEURST_E_LAUNCH;                                                  \
+    }                                                                          \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t dtype_size(int dt) { return dt == NEURST_BF16 ? 2 : 4; }
+
+// ---- scalar conversions ------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---- counter-based dropout RNG (same hash as oracle/ops.py:fmix32/keep_mask) --
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+// keep decision for flat element index idx under a call-site key
+__device__ __forceinline__ bool dropout_keep(uint32_t key, uint64_t idx, uint32_t thr) {
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = fmix32(lo ^ fmix32(hi ^ key));
+  return (h >> 8) >= thr;
+}
+static inline uint32_t rate_threshold(float rate) { return (uint32_t)(rate * 16777216.0f); }
+static inline float keep_scale(float rate) { return 1.0f / (1.0f - rate); }
+
+// ---- wave / block reductions ---------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x multiple of 64 (<= 1024); red must hold 16 floats
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+
+// ---- 16x16 MFMA micro-kernel, templated on the operand type ----------------------
+//  f32 : v_mfma_f32_16x16x4_f32   (exact fmaf chain; parity mode)
+//  bf16: v_mfma_f32_16x16x32_bf16 (perf mode)
+// Operand lane maps (cdna_hip_programming.md section 3):
+//  bf16 A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j = 0..7
+//  f32  A[row l&15][k = l>>4],      B[k = l>>4][col l&15]
+//  C/D  col = l&15, row = 4(l>>4) + reg
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  static constexpr int KS = 4;  // k per instruction
+  typedef float Frag;
+  // tile points at element [row0][k0] of a K-contiguous tile with leading dim ld (elements)
+  static __device__ __forceinline__ Frag load(const float* tile, int ld, int lane) {
+    return tile[(lane & 15) * ld + (lane >> 4)];
+  }
+  // element (row, k) lives at tile[k*ld + row]
+  static __device__ __forceinline__ Frag load_kstrided(const float* tile, int ld, int lane) {
+    return tile[(lane >> 4) * ld + (lane & 15)];
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {
+  static constexpr int KS = 32;
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ Frag load(const bf16_t* tile, int ld, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + (lane & 15) * ld + 8 * (lane >> 4));
+  }
+  static __device__ __forceinline__ Frag load_kstrided(const bf16_t* tile, int ld, int lane) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tile[(8 * (lane >> 4) + j) * ld + (lane & 15)];
+    return f;
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};

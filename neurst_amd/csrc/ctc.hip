@@ -1,0 +1,504 @@
+// Loss-side kernels (HBM roofline): a11 CTC alpha-beta, a12 greedy CTC decode, a13 shrink,
+// a17 label-smoothed cross entropy, a18 MSE, a2 loss mix.
+//
+// CTC follows tf.nn.ctc_loss (TF 1.15 ctc_loss_calculator; call site
+// st/models/TransformerTPE.py:96-102): softmax inside, blank = V-1, labels >= blank end
+// the label sequence, ctc_merge_repeated transitions, rows with U > T (or T == 0) give
+// loss 0 / grad 0, rows without a valid path give loss +inf and grad = softmax.
+// Traffic: logits are read ONCE from HBM (row cached in LDS), the gradient is written once
+// (softmax * scale), then only the S = 2U+1 label columns per frame are touched again.
+#include "common.h"
+
+struct CtcWs {
+  int32_t* lp;      // [B][Smax]  l' (labels with blanks)
+  int32_t* next;    // [B][Smax]  next state with the same symbol, -1 = none
+  int32_t* first;   // [B][Smax]  1 if no earlier state has the same symbol
+  int32_t* meta;    // [B][4]     S, active(1: run recursion), nopath, unused
+  float* logy;      // [B][T][Smax]
+  float* alpha;     // [B][T][Smax]  overwritten by the posteriors
+};
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static CtcWs carve_ws(void* ws, int64_t B, int64_t T, int64_t Smax) {
+  char* p = reinterpret_cast<char*>(ws);
+  CtcWs w;
+  w.lp = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * Smax);
+  w.next = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * Smax);
+  w.first = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * Smax);
+  w.meta = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * 4);
+  w.logy = reinterpret_cast<float*>(p); p += align256(sizeof(float) * B * T * Smax);
+  w.alpha = reinterpret_cast<float*>(p);
+  return w;
+}
+extern "C" int64_t neurst_ctc_workspace_bytes(int64_t B, int64_t T, int64_t Umax) {
+  int64_t Smax = 2 * Umax + 1;
+  return (int64_t)(3 * align256(sizeof(int32_t) * B * Smax) + align256(sizeof(int32_t) * B * 4) +
+                   2 * align256(sizeof(float) * B * T * Smax));
+}
+
+// ---- prep: one thread block per utterance builds l', the same-symbol chains and the feasibility flags
+__global__ void ctc_prep_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ len_labels,
+                                const int32_t* __restrict__ len_logits, CtcWs w, int64_t Umax, int64_t Smax, int64_t T, int V) {
+  const int64_t b = blockIdx.x;
+  int32_t* lp = w.lp + b * Smax;
+  int32_t* nx = w.next + b * Smax;
+  int32_t* fi = w.first + b * Smax;
+  __shared__ int Ueff;
+  const int blank = V - 1;
+  int U = len_labels[b];
+  U = U < 0 ? 0 : (U > Umax ? (int)Umax : U);
+  int Tb = len_logits[b];
+  Tb = Tb < 0 ? 0 : (Tb > T ? (int)T : Tb);
+  if (threadIdx.x == 0) {
+    int n = 0;
+    while (n < U && labels[b * Umax + n] < blank && labels[b * Umax + n] >= 0) ++n;
+    Ueff = n;
+  }
+  __syncthreads();
+  const int S = 2 * Ueff + 1;
+  for (int u = threadIdx.x; u < Smax; u += blockDim.x) lp[u] = (u < S && (u & 1)) ? labels[b * Umax + (u >> 1)] : blank;
+  __syncthreads();
+  for (int u = threadIdx.x; u < Smax; u += blockDim.x) {
+    int nxt = -1, first = 1;
+    if (u < S) {
+      for (int k = u + 1; k < S; ++k) if (lp[k] == lp[u]) { nxt = k; break; }
+      for (int k = 0; k < u; ++k) if (lp[k] == lp[u]) { first = 0; break; }
+    }
+    nx[u] = nxt;
+    fi[u] = first;
+  }
+  if (threadIdx.x == 0) {
+    w.meta[b * 4 + 0] = S;
+    w.meta[b * 4 + 1] = (Tb > 0 && U <= Tb) ? 1 : 0;   // ignore_longer_outputs_than_inputs / empty sequence
+    w.meta[b * 4 + 2] = 0;
+  }
+}
+
+// first-maximum argmax + online log-sum-exp over one row cached in LDS
+struct RowStat { float m, s; int arg; };
+__device__ __forceinline__ RowStat combine(RowStat a, RowStat b) {
+  RowStat r;
+  r.m = fmaxf(a.m, b.m);
+  r.s = (a.m == -INFINITY ? 0.f : a.s * expf(a.m - r.m)) + (b.m == -INFINITY ? 0.f : b.s * expf(b.m - r.m));
+  // argmax of the larger maximum, smallest index on ties
+  r.arg = (a.m > b.m) ? a.arg : ((b.m > a.m) ? b.arg : (a.arg < b.arg ? a.arg : b.arg));
+  return r;
+}
+__device__ __forceinline__ RowStat block_rowstat(const float* __restrict__ row, float* __restrict__ cache, int V, RowStat* red) {
+  RowStat st = {-INFINITY, 0.f, 0x7fffffff};
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    float x = row[i];
+    if (cache) cache[i] = x;
+    if (x > st.m) { st.s = (st.m == -INFINITY ? 0.f : st.s * expf(st.m - x)) + 1.f; st.m = x; st.arg = i; }
+    else st.s += expf(x - st.m);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    RowStat other = {__shfl_xor(st.m, o, 64), __shfl_xor(st.s, o, 64), __shfl_xor(st.arg, o, 64)};
+    st = combine(st, other);
+  }
+  const int wv = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wv] = st;
+  __syncthreads();
+  RowStat r = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = combine(r, red[i]);
+  return r;
+}
+
+// ---- A: per frame softmax (written as scaled gradient base), argmax and gathered log y
+template <typename TG>
+__global__ void __launch_bounds__(256) ctc_frame_kernel(const float* __restrict__ logits, const int32_t* __restrict__ len_logits,
+                                                       CtcWs w, TG* __restrict__ grad, int32_t* __restrict__ argmax, int64_t T, int V,
+                                                       int64_t Smax, float grad_scale, int use_cache) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cache = use_cache ? reinterpret_cast<float*>(smem) : nullptr;
+  __shared__ RowStat red[4];
+  const int64_t bt = blockIdx.x, b = bt / T, t = bt % T;
+  const float* row = logits + bt * V;
+  TG* grow = grad + bt * V;
+  int Tb = len_logits[b];
+  Tb = Tb > T ? (int)T : Tb;
+  if (t >= Tb) {
+    for (int i = threadIdx.x; i < V; i += blockDim.x) grow[i] = from_f32<TG>(0.f);
+    if (threadIdx.x == 0 && argmax) argmax[bt] = V - 1;
+    return;
+  }
+  RowStat st = block_rowstat(row, cache, V, red);
+  if (threadIdx.x == 0 && argmax) argmax[bt] = st.arg;
+  const bool active = w.meta[b * 4 + 1] != 0;
+  const float inv = 1.f / st.s;
+  const float* src = cache ? cache : row;
+  const float lse = st.m + logf(st.s);
+  if (active) {
+    const int S = w.meta[b * 4 + 0];
+    const int32_t* lp = w.lp + b * Smax;
+    float* ly = w.logy + bt * Smax;
+    for (int u = threadIdx.x; u < S; u += blockDim.x) ly[u] = src[lp[u]] - lse;
+  }
+  // in-place safe: every element is read (from the LDS cache or by the same thread) before it is written
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    float y = active ? expf(src[i] - st.m) * inv * grad_scale : 0.f;
+    grow[i] = from_f32<TG>(y);
+  }
+}
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  float m = fmaxf(a, fmaxf(b, c));
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// ---- B: alpha / beta recursion, one workgroup per utterance, one thread per state
+__global__ void ctc_alpha_beta_kernel(const int32_t* __restrict__ len_logits, CtcWs w, float* __restrict__ loss, int64_t T, int64_t Smax) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* buf = reinterpret_cast<float*>(smem);   // [2][Smax + 4], two leading / trailing -inf guards
+  const int64_t b = blockIdx.x;
+  const int u = threadIdx.x;
+  const int S = w.meta[b * 4 + 0];
+  int Tb = len_logits[b];
+  Tb = Tb > T ? (int)T : Tb;
+  if (!w.meta[b * 4 + 1]) { if (u == 0) loss[b] = 0.f; return; }
+  const int32_t* lp = w.lp + b * Smax;
+  const float* logy = w.logy + b * T * Smax;
+  float* alpha = w.alpha + b * T * Smax;
+  const int stride = (int)Smax + 4;
+  float* b0 = buf + 2;
+  float* b1 = buf + stride + 2;
+  for (int i = u; i < 2 * stride; i += blockDim.x) buf[i] = -INFINITY;
+  __syncthreads();
+  const bool live = u < S;
+  const int blank = lp[0];
+  const bool skip_in = live && u >= 2 && lp[u] != blank && lp[u] != lp[u - 2];        // u-2 -> u allowed
+  const bool skip_out = live && u + 2 < S && lp[u + 2] != blank && lp[u + 2] != lp[u];  // u -> u+2 allowed
+  float a = (live && u < 2) ? logy[u] : -INFINITY;
+  if (live) { alpha[u] = a; b0[u] = a; }
+  __syncthreads();
+  float* cur = b0;
+  float* nxt = b1;
+  for (int t = 1; t < Tb; ++t) {
+    if (live) {
+      a = lse3(cur[u], cur[u - 1], skip_in ? cur[u - 2] : -INFINITY) + logy[(int64_t)t * Smax + u];
+      alpha[(int64_t)t * Smax + u] = a;
+      nxt[u] = a;
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  const float logp = lse3(cur[S - 1], S >= 2 ? cur[S - 2] : -INFINITY, -INFINITY);
+  __syncthreads();
+  if (u == 0) {
+    loss[b] = -logp;
+    if (logp == -INFINITY) w.meta[b * 4 + 2] = 1;   // no valid path: gradient stays softmax
+  }
+  if (logp == -INFINITY) return;
+  // beta (emission at t excluded): beta[T-1][u] = 0 for the last two states
+  float be = (live && u >= S - 2) ? 0.f : -INFINITY;
+  if (live) {
+    int64_t o = (int64_t)(Tb - 1) * Smax + u;
+    float post = expf(alpha[o] + be - logp);
+    cur[u] = be + logy[o];
+    alpha[o] = post;
+  }
+  __syncthreads();
+  for (int t = Tb - 2; t >= 0; --t) {
+    if (live) {
+      be = lse3(cur[u], cur[u + 1], skip_out ? cur[u + 2] : -INFINITY);
+      int64_t o = (int64_t)t * Smax + u;
+      float post = expf(alpha[o] + be - logp);
+      nxt[u] = be + logy[o];
+      alpha[o] = post;
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+}
+
+// ---- C: grad[b,t,l'_u] -= scale * sum of the posteriors of all states emitting that symbol
+template <typename TG>
+__global__ void ctc_grad_fix_kernel(const int32_t* __restrict__ len_logits, CtcWs w, TG* __restrict__ grad, int64_t T, int V,
+                                    int64_t Smax, float grad_scale) {
+  const int64_t bt = blockIdx.x, b = bt / T, t = bt % T;
+  if (!w.meta[b * 4 + 1] || w.meta[b * 4 + 2]) return;
+  int Tb = len_logits[b];
+  if (t >= Tb) return;
+  const int S = w.meta[b * 4 + 0];
+  const int32_t* lp = w.lp + b * Smax;
+  const int32_t* nx = w.next + b * Smax;
+  const int32_t* fi = w.first + b * Smax;
+  const float* post = w.alpha + bt * Smax;
+  TG* grow = grad + bt * V;
+  for (int u = threadIdx.x; u < S; u += blockDim.x) {
+    if (!fi[u]) continue;
+    float s = 0.f;
+    for (int k = u; k >= 0; k = nx[k]) s += post[k];
+    grow[lp[u]] = from_f32<TG>(to_f32<TG>(grow[lp[u]]) - s * grad_scale);
+  }
+}
+
+extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_logits, const int32_t* labels, const int32_t* len_labels,
+                                       float* loss, void* grad, int grad_dtype, int32_t* argmax, void* workspace, int64_t B, int64_t T,
+                                       int64_t V, int64_t Umax, float grad_scale, void* stream) {
+  NEURST_CHECK_ARG(logits && len_logits && labels && len_labels && loss && grad && workspace, "ctc: null pointer");
+  NEURST_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0, "ctc: bad shape");
+  const int64_t Smax = 2 * Umax + 1;
+  NEURST_CHECK_ARG(Smax <= 1024, "ctc: label length %ld too long (2U+1 must be <= 1024)", (long)Umax);
+  NEURST_CHECK_ARG(grad_dtype == NEURST_F32 || (const void*)grad != (const void*)logits, "ctc: bf16 gradient cannot alias the logits");
+  hipStream_t s = as_stream(stream);
+  CtcWs w = carve_ws(workspace, B, T, Smax);
+  ctc_prep_kernel<<<(int)B, 128, 0, s>>>(labels, len_labels, len_logits, w, Umax, Smax, T, (int)V);
+  NEURST_CHECK_LAUNCH("ctc_prep");
+  const int use_cache = V * sizeof(float) <= 64 * 1024;
+  const size_t shm = use_cache ? V * sizeof(float) : 0;
+  NEURST_CHECK_ARG(use_cache || (const void*)grad != (const void*)logits, "ctc: in-place gradient needs V*4 <= 64 KiB");
+  if (grad_dtype == NEURST_BF16)
+    ctc_frame_kernel<bf16_t><<<(unsigned)(B * T), 256, shm, s>>>(logits, len_logits, w, (bf16_t*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
+  else
+    ctc_frame_kernel<float><<<(unsigned)(B * T), 256, shm, s>>>(logits, len_logits, w, (float*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
+  NEURST_CHECK_LAUNCH("ctc_frame");
+  int nthr = (int)((Smax + 63) / 64 * 64);
+  ctc_alpha_beta_kernel<<<(int)B, nthr, 2 * (Smax + 4) * sizeof(float), s>>>(len_logits, w, loss, T, Smax);
+  NEURST_CHECK_LAUNCH("ctc_alpha_beta");
+  if (grad_dtype == NEURST_BF16)
+    ctc_grad_fix_kernel<bf16_t><<<(unsigned)(B * T), 128, 0, s>>>(len_logits, w, (bf16_t*)grad, T, (int)V, Smax, grad_scale);
+  else
+    ctc_grad_fix_kernel<float><<<(unsigned)(B * T), 128, 0, s>>>(len_logits, w, (float*)grad, T, (int)V, Smax, grad_scale);
+  NEURST_CHECK_LAUNCH("ctc_grad_fix");
+  return NEURST_OK;
+}
+
+// ---- per-row first-maximum argmax (inference)
+__global__ void __launch_bounds__(256) argmax_rows_kernel(const float* __restrict__ logits, int32_t* __restrict__ argmax, int V) {
+  __shared__ RowStat red[4];
+  RowStat st = block_rowstat(logits + (int64_t)blockIdx.x * V, nullptr, V, red);
+  if (threadIdx.x == 0) argmax[blockIdx.x] = st.arg;
+}
+extern "C" int neurst_argmax_rows(const float* logits, int32_t* argmax, int64_t rows, int64_t V, void* stream) {
+  NEURST_CHECK_ARG(rows > 0 && V > 0, "argmax_rows: bad shape");
+  argmax_rows_kernel<<<(unsigned)rows, 256, 0, as_stream(stream)>>>(logits, argmax, (int)V);
+  NEURST_CHECK_LAUNCH("argmax_rows");
+  return NEURST_OK;
+}
+
+// ---------------------------------------------------------------- a12 / a13: keep flags + compaction
+// index[b][j] = source frame of the j-th kept frame, -1 beyond the count
+__global__ void __launch_bounds__(256) keep_index_kernel(const int32_t* __restrict__ argmax, const int32_t* __restrict__ lens,
+                                                        int32_t* __restrict__ index, int32_t* __restrict__ new_len, int64_t T,
+                                                        int32_t blank) {
+  __shared__ int counts[256];
+  const int64_t b = blockIdx.x;
+  const int32_t* am = argmax + b * T;
+  int32_t* idx = index + b * T;
+  int len = lens[b];
+  len = len > T ? (int)T : len;
+  const int per = (int)((T + 255) / 256);
+  const int t0 = threadIdx.x * per, t1 = (t0 + per < T) ? t0 + per : (int)T;
+  int c = 0;
+  for (int t = t0; t < t1; ++t) {
+    int prev = t == 0 ? blank : am[t - 1];
+    c += (t < len && am[t] != blank && am[t] != prev) ? 1 : 0;
+  }
+  counts[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { int x = counts[i]; counts[i] = run; run += x; }
+    new_len[b] = run;
+  }
+  __syncthreads();
+  int pos = counts[threadIdx.x];
+  for (int t = t0; t < t1; ++t) {
+    int prev = t == 0 ? blank : am[t - 1];
+    if (t < len && am[t] != blank && am[t] != prev) idx[pos++] = t;
+  }
+  __syncthreads();
+  const int total = new_len[b];
+  for (int j = total + threadIdx.x; j < T; j += blockDim.x) idx[j] = -1;
+}
+__global__ void greedy_gather_kernel(const int32_t* __restrict__ argmax, int32_t* __restrict__ out, int64_t B, int64_t T) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  int64_t b = i / T;
+  int src = out[i];
+  out[i] = src >= 0 ? argmax[b * T + src] : 0;
+}
+extern "C" int neurst_ctc_greedy(const int32_t* argmax, const int32_t* len_logits, int32_t* out, int32_t* out_len, int64_t B, int64_t T,
+                                 int32_t blank, void* stream) {
+  NEURST_CHECK_ARG(B > 0 && T > 0, "ctc_greedy: bad shape");
+  keep_index_kernel<<<(int)B, 256, 0, as_stream(stream)>>>(argmax, len_logits, out, out_len, T, blank);
+  NEURST_CHECK_LAUNCH("ctc_greedy_index");
+  greedy_gather_kernel<<<(int)cdiv64(B * T, 256), 256, 0, as_stream(stream)>>>(argmax, out, B, T);
+  NEURST_CHECK_LAUNCH("ctc_greedy_gather");
+  return NEURST_OK;
+}
+extern "C" int neurst_shrink_index(const int32_t* argmax, const int32_t* lens, int32_t* index, int32_t* new_len, int64_t B, int64_t T,
+                                   int32_t blank, void* stream) {
+  NEURST_CHECK_ARG(B > 0 && T > 0, "shrink_index: bad shape");
+  keep_index_kernel<<<(int)B, 256, 0, as_stream(stream)>>>(argmax, lens, index, new_len, T, blank);
+  NEURST_CHECK_LAUNCH("shrink_index");
+  return NEURST_OK;
+}
+
+template <typename T>
+__global__ void shrink_gather_kernel(const T* __restrict__ x, const int32_t* __restrict__ index, T* __restrict__ out, int64_t B, int64_t Tn,
+                                     int64_t Tout, int64_t D) {
+  const int64_t total = B * Tout * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t d = i % D, r = i / D;
+    int64_t j = r % Tout, b = r / Tout;
+    int src = index[b * Tn + j];
+    out[i] = src >= 0 ? x[(b * Tn + src) * D + d] : from_f32<T>(0.f);
+  }
+}
+template <typename T>
+__global__ void shrink_scatter_kernel(const T* __restrict__ dout, const int32_t* __restrict__ index, T* __restrict__ dx, int64_t B, int64_t Tn,
+                                      int64_t Tout, int64_t D) {
+  const int64_t total = B * Tout * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t d = i % D, r = i / D;
+    int64_t j = r % Tout, b = r / Tout;
+    int src = index[b * Tn + j];
+    if (src >= 0) dx[(b * Tn + src) * D + d] = dout[i];
+  }
+}
+static inline int sgrid(int64_t n) { int64_t g = cdiv64(n, 256); return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+extern "C" int neurst_shrink_fwd(const void* x, const int32_t* index, void* out, int64_t B, int64_t T, int64_t Tout, int64_t D, int dtype,
+                                 void* stream) {
+  NEURST_CHECK_ARG(B > 0 && T > 0 && Tout > 0 && Tout <= T && D > 0, "shrink_fwd: bad shape");
+  if (dtype == NEURST_BF16) shrink_gather_kernel<bf16_t><<<sgrid(B * Tout * D), 256, 0, as_stream(stream)>>>((const bf16_t*)x, index, (bf16_t*)out, B, T, Tout, D);
+  else shrink_gather_kernel<float><<<sgrid(B * Tout * D), 256, 0, as_stream(stream)>>>((const float*)x, index, (float*)out, B, T, Tout, D);
+  NEURST_CHECK_LAUNCH("shrink_fwd");
+  return NEURST_OK;
+}
+extern "C" int neurst_shrink_bwd(const void* dout, const int32_t* index, void* dx, int64_t B, int64_t T, int64_t Tout, int64_t D, int dtype,
+                                 void* stream) {
+  NEURST_CHECK_ARG(B > 0 && T > 0 && Tout > 0 && Tout <= T && D > 0, "shrink_bwd: bad shape");
+  hipError_t e = hipMemsetAsync(dx, 0, (size_t)(B * T * D) * dtype_size(dtype), as_stream(stream));
+  if (e != hipSuccess) { neurst_set_error("shrink_bwd: memset failed: %s", hipGetErrorString(e)); return NEURST_E_LAUNCH; }
+  if (dtype == NEURST_BF16) shrink_scatter_kernel<bf16_t><<<sgrid(B * Tout * D), 256, 0, as_stream(stream)>>>((const bf16_t*)dout, index, (bf16_t*)dx, B, T, Tout, D);
+  else shrink_scatter_kernel<float><<<sgrid(B * Tout * D), 256, 0, as_stream(stream)>>>((const float*)dout, index, (float*)dx, B, T, Tout, D);
+  NEURST_CHECK_LAUNCH("shrink_bwd");
+  return NEURST_OK;
+}
+
+// ---------------------------------------------------------------- a17 label-smoothed cross entropy
+template <typename TG>
+__global__ void __launch_bounds__(256) ls_xent_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                     const int32_t* __restrict__ len_labels, float* __restrict__ xent, TG* __restrict__ grad,
+                                                     int64_t L, int V, float conf, float grad_scale, int use_cache) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cache = use_cache ? reinterpret_cast<float*>(smem) : nullptr;
+  __shared__ RowStat red[4];
+  __shared__ float fred[16];
+  const int64_t bl = blockIdx.x, b = bl / L, l = bl % L;
+  const float* row = logits + bl * V;
+  TG* grow = grad + bl * V;
+  const int len = len_labels[b];
+  if (l >= len) {
+    for (int i = threadIdx.x; i < V; i += blockDim.x) grow[i] = from_f32<TG>(0.f);
+    if (threadIdx.x == 0) xent[bl] = 0.f;
+    return;
+  }
+  RowStat st = block_rowstat(row, cache, V, red);
+  const float* src = cache ? cache : row;
+  float zs = 0.f;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) zs += src[i];
+  zs = block_sum(zs, fred);
+  const float lse = st.m + logf(st.s);
+  const float low = (1.0f - conf) / (float)(V - 1);
+  const float normalizing = -(conf * logf(conf) + (float)(V - 1) * low * logf(low + 1e-20f));
+  int lab = labels[bl];
+  lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+  const float inv_len = 1.0f / (float)len;
+  if (threadIdx.x == 0) {
+    float sum_logp = zs - (float)V * lse;
+    float x = -(low * sum_logp + (conf - low) * (src[lab] - lse)) - normalizing;
+    xent[bl] = x * inv_len;
+  }
+  const float sumsoft = conf + (float)(V - 1) * low;
+  const float g = grad_scale * inv_len;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    float p = expf(src[i] - lse);
+    float soft = (i == lab) ? conf : low;
+    grow[i] = from_f32<TG>(g * (p * sumsoft - soft));
+  }
+}
+extern "C" int neurst_ls_xent_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* len_labels, float* xent, void* grad,
+                                      int grad_dtype, int64_t B, int64_t L, int64_t V, float confidence, float grad_scale, void* stream) {
+  NEURST_CHECK_ARG(logits && labels && len_labels && xent && grad, "ls_xent: null pointer");
+  NEURST_CHECK_ARG(B > 0 && L > 0 && V > 1 && confidence > 0.f && confidence <= 1.f, "ls_xent: bad args");
+  const int use_cache = V * sizeof(float) <= 64 * 1024;
+  NEURST_CHECK_ARG(use_cache || (const void*)grad != (const void*)logits, "ls_xent: in-place gradient needs V*4 <= 64 KiB");
+  NEURST_CHECK_ARG(grad_dtype == NEURST_F32 || (const void*)grad != (const void*)logits, "ls_xent: bf16 gradient cannot alias the logits");
+  const size_t shm = use_cache ? V * sizeof(float) : 0;
+  if (grad_dtype == NEURST_BF16)
+    ls_xent_kernel<bf16_t><<<(unsigned)(B * L), 256, shm, as_stream(stream)>>>(logits, labels, len_labels, xent, (bf16_t*)grad, L, (int)V, confidence, grad_scale, use_cache);
+  else
+    ls_xent_kernel<float><<<(unsigned)(B * L), 256, shm, as_stream(stream)>>>(logits, labels, len_labels, xent, (float*)grad, L, (int)V, confidence, grad_scale, use_cache);
+  NEURST_CHECK_LAUNCH("ls_xent");
+  return NEURST_OK;
+}
+
+// ---------------------------------------------------------------- a18 MSE
+extern "C" int64_t neurst_mse_blocks(int64_t n) { int64_t g = cdiv64(n, 1024); return g > 1024 ? 1024 : (g < 1 ? 1 : g); }
+template <typename T, typename TL>
+__global__ void __launch_bounds__(256) mse_kernel(const T* __restrict__ pred, const TL* __restrict__ label, float* __restrict__ partial,
+                                                 T* __restrict__ dpred, int64_t n, float gs) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float d = to_f32<T>(pred[i]) - to_f32<TL>(label[i]);
+    s += d * d;
+    dpred[i] = from_f32<T>(gs * d);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" int neurst_mse_fwd_bwd(const void* pred, const void* label, int label_dtype, float* partial, void* dpred, int64_t n,
+                                  float grad_scale, int dtype, void* stream) {
+  NEURST_CHECK_ARG(pred && label && partial && dpred && n > 0, "mse: bad args");
+  int grid = (int)neurst_mse_blocks(n);
+  float gs = grad_scale * 2.0f / (float)n;
+  hipStream_t s = as_stream(stream);
+  if (dtype == NEURST_BF16) {
+    if (label_dtype == NEURST_BF16) mse_kernel<bf16_t, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)pred, (const bf16_t*)label, partial, (bf16_t*)dpred, n, gs);
+    else mse_kernel<bf16_t, float><<<grid, 256, 0, s>>>((const bf16_t*)pred, (const float*)label, partial, (bf16_t*)dpred, n, gs);
+  } else {
+    NEURST_CHECK_ARG(label_dtype == NEURST_F32, "mse: fp32 predictions need fp32 labels");
+    mse_kernel<float, float><<<grid, 256, 0, s>>>((const float*)pred, (const float*)label, partial, (float*)dpred, n, gs);
+  }
+  NEURST_CHECK_LAUNCH("mse");
+  return NEURST_OK;
+}
+
+// ---------------------------------------------------------------- a2 loss mix
+__global__ void loss_combine_kernel(const float* __restrict__ xent, const float* __restrict__ ctc, const float* __restrict__ mse_partial,
+                                    int64_t n_partial, int64_t mse_numel, int64_t B, int64_t L, float w_ast, float w_ctc, float w_kd,
+                                    float* __restrict__ out4) {
+  __shared__ float red[16];
+  float mse = 0.f;
+  if (mse_partial) {
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n_partial; i += blockDim.x) s += mse_partial[i];
+    mse = block_sum(s, red) / (float)mse_numel;
+  }
+  float s_ast = 0.f, s_ctc = 0.f, s_tot = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+    float ce = 0.f;
+    if (xent) for (int64_t l = 0; l < L; ++l) ce += xent[b * L + l];
+    float c = ctc ? ctc[b] : 0.f;
+    s_ast += ce; s_ctc += c;
+    s_tot += w_ctc * c + w_kd * mse + w_ast * ce;
+  }
+  s_ast = block_sum(s_ast, red);
+  s_ctc = block_sum(s_ctc, red);
+  s_tot = block_sum(s_tot, red);
+  if (threadIdx.x == 0) {
+    out4[0] = s_tot / (float)B; out4[1] = s_ast / (float)B; out4[2] = s_ctc / (float)B; out4[3] = mse;
+  }
+}
+extern "C" int neurst_loss_combine(const float* xent, const float* ctc, const float* mse_partial, int64_t n_partial, int64_t mse_numel,
+                                   int64_t B, int64_t L, float w_ast, float w_ctc, float w_kd, float* out4, void* stream) {
+  NEURST_CHECK_ARG(B > 0 && out4, "loss_combine: bad args");
+  loss_combine_kernel<<<1, 256, 0, as_stream(stream)>>>(xent, ctc, mse_partial, n_partial, mse_numel > 0 ? mse_numel : 1, B, L, w_ast, w_ctc, w_kd, out4);
+  NEURST_CHECK_LAUNCH("loss_combine");
+  return NEURST_OK;
+}

@@ -1,0 +1,231 @@
+"""Execution context that stands in for the pieces of TensorFlow the reference leans on:
+variable scopes + `tf.get_variable` (a flat-arena VariableStore with the TF variable
+names), and `optimizer.compute_gradients` (a reverse-mode Tape whose nodes launch the
+backward HIP kernels).  No arithmetic happens here - only bookkeeping of device buffers.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from ... import ops
+
+ALIGN = 64  # every parameter starts on a 256-byte boundary of the fp32 arena (128 B of the bf16 shadow)
+
+
+class Param:
+    __slots__ = ('name', 'shape', 'offset', 'size', 'kind', 'store')
+
+    def __init__(self, name, shape, offset, kind, store):
+        self.name, self.shape, self.offset, self.kind, self.store = name, tuple(shape), offset, kind, store
+        self.size = int(np.prod(shape))
+
+    def _view(self, arena):
+        return arena[self.offset:self.offset + self.size].view(self.shape)
+
+    @property
+    def master(self):      # fp32 master copy
+        return self._view(self.store.params)
+
+    @property
+    def w(self):           # operand in the compute dtype (bf16 shadow or the fp32 master)
+        return self._view(self.store.shadow if self.store.shadow is not None else self.store.params)
+
+    @property
+    def grad(self):        # fp32 gradient (accumulated into; zeroed at the start of a step)
+        return self._view(self.store.grads)
+
+
+class VariableStore:
+    """All trainable variables in one fp32 arena (+ grads, Adam m/v, optional bf16 shadow),
+    laid out in creation (= forward) order so backward completes gradient buckets from the
+    end of the arena towards the start."""
+
+    def __init__(self, specs, device, compute_dtype, seed=1):
+        self.device = device
+        self.compute_dtype = compute_dtype
+        self.vars = {}
+        off = 0
+        for name, shape, kind in specs:
+            if name in self.vars:
+                continue
+            self.vars[name] = Param(name, shape, off, kind, self)
+            off += -(-int(np.prod(shape)) // ALIGN) * ALIGN
+        self.total = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device) if compute_dtype == ops.BF16 else None
+        self.adam_t = 0
+        self.initialize(seed)
+
+    def initialize(self, seed):
+        """Glorot-uniform for matrices (TF default of get_variable), ones / zeros for LN and biases."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.total, np.float32)
+        for p in self.vars.values():
+            if p.kind == 'glorot':
+                if len(p.shape) == 2:
+                    fi, fo = p.shape
+                else:
+                    rf = int(np.prod(p.shape[:-2]))
+                    fi, fo = rf * p.shape[-2], rf * p.shape[-1]
+                lim = np.sqrt(6.0 / (fi + fo))
+                host[p.offset:p.offset + p.size] = rng.uniform(-lim, lim, size=p.size).astype(np.float32)
+            elif p.kind == 'ones':
+                host[p.offset:p.offset + p.size] = 1.0
+        self.params.copy_(torch.from_numpy(host))
+        self.sync_shadow()
+
+    def sync_shadow(self):
+        if self.shadow is not None:
+            ops.cast_f32_to_bf16(self.params, self.shadow)
+
+    def load_params(self, named):
+        """named: {tf_variable_name: numpy array} (same names / layouts as the reference's checkpoint)."""
+        host = self.params.cpu().numpy()
+        for name, arr in named.items():
+            p = self.vars[name]
+            assert tuple(arr.shape) == p.shape, (name, arr.shape, p.shape)
+            host[p.offset:p.offset + p.size] = np.asarray(arr, np.float32).reshape(-1)
+        self.params.copy_(torch.from_numpy(host))
+        self.sync_shadow()
+
+    def export(self, arena=None):
+        host = (self.params if arena is None else arena).float().cpu().numpy()
+        return {n: host[p.offset:p.offset + p.size].reshape(p.shape).copy() for n, p in self.vars.items()}
+
+    def export_grads(self):
+        return self.export(self.grads)
+
+    def zero_grads(self):
+        self.grads.zero_()   # hipMemsetAsync on the current stream
+
+    def get(self, name, shape=None):
+        p = self.vars[name]
+        if shape is not None:
+            assert tuple(shape) == p.shape, (name, shape, p.shape)
+        return p
+
+
+class Tape:
+    """Reverse-mode record of one forward pass.  `push(fn)` registers the backward launch of an
+    op; gradients of intermediate tensors are kept by tensor identity; an op whose output
+    gradient must be added to an existing one either accumulates in its kernel (GEMM) or goes
+    through `accumulate`."""
+
+    def __init__(self):
+        self.nodes = []
+        self.grads = {}
+        self.keep = {}
+        self.relu_outputs = set()   # ids of tensors produced by a fused ReLU: their gradient is gated where it is produced
+
+    def push(self, fn):
+        self.nodes.append(fn)
+
+    def grad(self, t):
+        return self.grads.get(id(t))
+
+    def pop(self, t):
+        self.keep.pop(id(t), None)
+        return self.grads.pop(id(t), None)
+
+    def has(self, t):
+        return id(t) in self.grads
+
+    def set(self, t, g):
+        self.keep[id(t)] = t
+        self.grads[id(t)] = g
+
+    def accumulate(self, t, g):
+        if id(t) in self.grads:
+            ops.add_inplace(self.grads[id(t)], g)
+        else:
+            self.set(t, g)
+
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes.clear()
+
+
+class Graph:
+    """One model's execution context (TF: default graph + variable scope + train/eval flag)."""
+
+    def __init__(self, store, dtype, seed=0):
+        self.store = store
+        self.dtype = dtype
+        self.seed = seed
+        self.step = 0
+        self.tape = None
+        self.scopes = []
+        self.auto_site = 10_000
+        self.name_counts = {}
+        self.dropout_enabled = True
+        self.on_param_grad = None   # callback(Param) once a parameter's gradient kernels are enqueued
+
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        self.scopes.append(name)
+        try:
+            yield
+        finally:
+            self.scopes.pop()
+
+    def default_scope(self, default_name):
+        """tf.variable_scope(None, default_name=...): first use keeps the name, later uses in the
+        same enclosing scope get _1, _2, ... (reset by begin_forward)."""
+        k = (self.scope_name(), default_name)
+        n = self.name_counts.get(k, 0)
+        self.name_counts[k] = n + 1
+        return self.variable_scope(default_name if n == 0 else '{}_{}'.format(default_name, n))
+
+    def begin_forward(self, tape=None, step=None):
+        self.name_counts = {}
+        self.auto_site = 10_000
+        self.tape = tape
+        if step is not None:
+            self.step = step
+
+    def scope_name(self):
+        return '/'.join(s for s in self.scopes if s)
+
+    def get_variable(self, name, shape=None):
+        full = self.scope_name() + '/' + name if self.scopes else name
+        return self.store.get(full, shape)
+
+    def key(self, site=None):
+        if site is None:
+            site = self.auto_site
+            self.auto_site += 1
+        return ops.site_key(self.seed, site, self.step)
+
+    def rate(self, r):
+        return float(r) if (self.dropout_enabled and r) else 0.0
+
+    def param_grad_done(self, p):
+        if self.on_param_grad is not None:
+            self.on_param_grad(p)
+
+
+_current = []
+
+
+def current():
+    if not _current:
+        raise RuntimeError('no active Graph: layer functions must run inside `with use_graph(g):`')
+    return _current[-1]
+
+
+@contextlib.contextmanager
+def use_graph(g):
+    _current.append(g)
+    try:
+        yield g
+    finally:
+        _current.pop()
+
+
+def variable_scope(name):
+    return current().variable_scope(name)

@@ -1,0 +1,362 @@
+"""-m gpu: every HIP kernel through the C ABI against the numpy oracle on the same seeded inputs.
+fp32 mode: 1e-5 relative (north_star); bf16 mode: the tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from neurst_amd import ops
+    DEV = torch.device('cuda:0')
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def host(t):
+    return t.float().cpu().numpy() if t.dtype in (torch.bfloat16, torch.float32) else t.cpu().numpy()
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_mma_fragment_layout(dtype):
+    # A = identity-like with an ASYMMETRIC B catches swapped row/col maps
+    rng = np.random.default_rng(0)
+    K = 64
+    A = rng.integers(-3, 4, size=(16, K)).astype(np.float32)
+    Bt = rng.integers(-3, 4, size=(16, K)).astype(np.float32)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    C = host(ops.selftest_mma(dev(A, td), dev(Bt, td)))
+    assert np.array_equal(C, A @ Bt.T)
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize('M,N,K', [(200, 136, 72), (37, 11, 16), (129, 257, 333), (256, 128, 130)])
+def test_gemm_variants(dtype, tol, ta, tb, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    if dtype == 'bf16':
+        A, B = bf16_round(A), bf16_round(B)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64) + bias
+    C = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(dev(A, td), dev(B, td), C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias))
+    assert relerr(host(C), ref) < (tol if dtype == 'f32' else 1e-5), (dtype, ta, tb)
+    # relu + accumulate + bf16 output
+    C2 = torch.full((M, N), 0.5, dtype=td, device=DEV)
+    ops.gemm(dev(A, td), dev(B, td), C2, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias), relu=True, accumulate=True)
+    assert relerr(host(C2), np.maximum(ref, 0) + 0.5) < tol
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_gemm_splitk_and_relu_gate(dtype):
+    rng = np.random.default_rng(5)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    M, N, K = 96, 80, 5000
+    A = bf16_round(rng.standard_normal((K, M)) * 0.1)
+    B = bf16_round(rng.standard_normal((K, N)) * 0.1)
+    C = torch.ones((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(dev(A, td), dev(B, td), C, M, N, K, M, N, N, True, False, accumulate=True, split_k=7)
+    assert relerr(host(C), A.T.astype(np.float64) @ B + 1.0) < 1e-5
+    gate = bf16_round(rng.standard_normal((M, N)))
+    X = bf16_round(rng.standard_normal((M, 64)))
+    W = bf16_round(rng.standard_normal((64, N)))
+    C3 = torch.empty((M, N), dtype=td, device=DEV)
+    ops.gemm(dev(X, td), dev(W, td), C3, M, N, 64, 64, N, N, False, False, relu_src=dev(gate, td))
+    assert relerr(host(C3), (X @ W) * (gate > 0)) < (1e-5 if dtype == 'f32' else 1e-2)
+
+
+def test_colsum():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1000, 70)).astype(np.float32)
+    out = torch.ones(70, dtype=torch.float32, device=DEV)
+    ops.colsum(dev(x), out, accumulate=True)
+    assert relerr(host(out), x.sum(0) + 1) < 1e-5
+
+
+def test_splice_downsample_matches_per_utterance_reference():
+    rng = np.random.default_rng(2)
+    B, Traw, F = 3, 23, 5
+    lens = np.array([23, 10, 1], np.int32)
+    x = rng.standard_normal((B, Traw, F)).astype(np.float32) * (np.arange(Traw)[None, :, None] < lens[:, None, None])
+    ref, ref_len = O.splice_downsample_batch(x, lens, 5, 3)
+    out, ln = ops.splice_downsample(dev(x), dev(lens), 5, 3, ops.F32)
+    assert np.array_equal(host(out), ref) and np.array_equal(host(ln), ref_len)
+
+
+def test_specaug_params_and_apply():
+    rng = np.random.default_rng(3)
+    B, T, v = 4, 60, 48
+    lens = np.array([60, 33, 7, 50])
+    x = (rng.standard_normal((B, T, v)).astype(np.float32) + 3.0) * (np.arange(T)[None, :, None] < lens[:, None, None])
+    key = 12345
+    p = host(ops.specaug_params(dev(x), 30, 40, 0.2, key))
+    ref_p = O.specaug_sample_params(O.specaug_real_length(x), v, 30, 40, 0.2, key)
+    assert np.array_equal(p, ref_p)
+    y = host(ops.specaug_apply_(dev(x), dev(ref_p)))
+    assert np.array_equal(y, O.specaug_apply(x, ref_p))
+
+
+@pytest.mark.parametrize('rate', [0.0, 0.25])
+def test_timing_dropout_fwd_bwd(rate):
+    rng = np.random.default_rng(4)
+    B, T, C = 2, 37, 24
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    key = O.site_key(1, 2, 3)
+    y = host(ops.add_timing_dropout(dev(x), ops.F32, rate, key))
+    ref, m = O.dropout_fwd(x + O.timing_signal(T, C), rate, key)
+    assert relerr(y, ref) < 1e-6
+    dy = rng.standard_normal((B, T, C)).astype(np.float32)
+    dx = host(ops.dropout_bwd(dev(dy), rate, key))
+    assert relerr(dx, dy if m is None else dy * m) < 1e-6
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('C,rate', [(768, 0.0), (512, 0.1), (24, 0.1), (16, 0.0), (100, 0.0)])
+def test_dropout_add_layernorm(dtype, tol, C, rate):
+    rng = np.random.default_rng(C)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    B, T = 3, 41
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    y = rng.standard_normal((B, T, C)).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    lens = np.array([41, 17, 0], np.int32)
+    if dtype == 'bf16':
+        x, y = bf16_round(x), bf16_round(y)
+    key = O.site_key(7, 100, 0)
+    keep = (np.arange(T)[None, :] < lens[:, None]).astype(np.float32)[..., None]
+    ref, cache = O.residual_fwd(x, y, gam, bet, rate, key)
+    yz = dev(y, td)
+    out, mean, rstd = ops.dropout_add_layernorm_fwd(dev(x, td), yz, dev(gam), dev(bet), rate, key, dev(lens), T)
+    assert relerr(host(out), ref * keep) < tol
+    dout = rng.standard_normal((B, T, C)).astype(np.float32)
+    if dtype == 'bf16':
+        dout = bf16_round(dout)
+    dz_ref, dy_ref, dg_ref, db_ref = O.residual_bwd(dout * keep, cache, gam)
+    dg = torch.zeros(C, dtype=torch.float32, device=DEV)
+    db = torch.zeros(C, dtype=torch.float32, device=DEV)
+    dz, dy = ops.dropout_add_layernorm_bwd(dev(dout, td), yz, dev(gam), mean, rstd, dg, db, rate, key, dev(lens), T)
+    assert relerr(host(dz), dz_ref) < tol and relerr(host(dy), dy_ref) < tol
+    assert relerr(host(dg), dg_ref) < tol and relerr(host(db), db_ref) < tol
+
+
+ATT_CASES = [
+    # B, H, Tq, Tk, dh, mode, rate
+    (2, 2, 37, 37, 8, 'keypad', 0.0),
+    (2, 8, 130, 130, 96, 'keypad', 0.1),
+    (3, 4, 70, 70, 64, 'causal', 0.1),
+    (2, 4, 9, 150, 192, 'none', 0.1),
+    (2, 2, 40, 100, 32, 'keypad', 0.0),
+    (1, 2, 65, 64, 128, 'none', 0.0),
+]
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 2e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('B,H,Tq,Tk,dh,mode,rate', ATT_CASES)
+def test_attention_fwd_bwd(dtype, tol, B, H, Tq, Tk, dh, mode, rate):
+    rng = np.random.default_rng(Tq * 7 + dh)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    d = H * dh
+    q = rng.standard_normal((B, Tq, d)).astype(np.float32)
+    k = rng.standard_normal((B, Tk, d)).astype(np.float32)
+    v = rng.standard_normal((B, Tk, d)).astype(np.float32)
+    do = rng.standard_normal((B, Tq, d)).astype(np.float32)
+    if dtype == 'bf16':
+        q, k, v, do = bf16_round(q), bf16_round(k), bf16_round(v), bf16_round(do)
+    lens = np.array([Tk, max(Tk // 3, 1), 0][:B], np.int32)
+    mm = {'none': O.MASK_NONE, 'keypad': O.MASK_KEYPAD, 'causal': O.MASK_CAUSAL}[mode]
+    key = O.site_key(3, 101, 1)
+    ref, cache = O.mha_core_fwd(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), H, mm, lens, rate, key)
+    dq_r, dk_r, dv_r = O.mha_core_bwd(do.astype(np.float64), cache)
+    qd, kd, vd = dev(q, td), dev(k, td), dev(v, td)
+    ld = dev(lens) if mode == 'keypad' else None
+    o, lse = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key)
+    assert relerr(host(o), ref) < tol
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.mha_bwd(qd, kd, vd, o, dev(do, td), lse, dq, dk, dv, d, d, d, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key)
+    assert relerr(host(dq), dq_r) < tol and relerr(host(dk), dk_r) < tol and relerr(host(dv), dv_r) < tol
+
+
+def test_attention_packed_qkv_strides():
+    rng = np.random.default_rng(11)
+    B, H, T, dh = 2, 2, 50, 16
+    d = H * dh
+    qkv = rng.standard_normal((B, T, 3 * d)).astype(np.float32)
+    lens = np.array([50, 20], np.int32)
+    ref, _ = O.mha_core_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, O.MASK_KEYPAD, lens)
+    t = dev(qkv).view(-1)
+    o, _ = ops.mha_fwd(t, t[d:], t[2 * d:], 3 * d, 3 * d, 3 * d, B, H, T, T, dh, ops.MASK_KEYPAD, dev(lens), 0.0, 0)
+    assert relerr(host(o), ref) < 2e-5
+
+
+def test_ctc_loss_grad_argmax_greedy():
+    rng = np.random.default_rng(0)
+    B, T, V, U = 6, 50, 37, 7
+    logits = (rng.standard_normal((B, T, V)) * 2).astype(np.float32)
+    labels = rng.integers(1, V - 1, size=(B, U)).astype(np.int32)
+    labels[0, :3] = 5                      # repeats
+    labels[4, :] = 2                       # all repeats: U + repeats > T below -> no valid path
+    len_labels = np.array([7, 4, 1, 7, 7, 6], np.int32)
+    len_logits = np.array([50, 30, 9, 5, 10, 50], np.int32)   # row 3: U > T -> ignored; row 4: no valid path
+    labels[5, 4] = V - 1                   # a label >= blank terminates the sequence (TF PopulateLPrimes)
+    ref_loss, ref_grad = O.ctc_loss_fwd_bwd(logits.astype(np.float64), len_logits, labels, len_labels)
+    loss, grad, am = ops.ctc_loss_fwd_bwd(dev(logits), dev(len_logits), dev(labels), dev(len_labels), ops.F32, 0.25)
+    loss, grad, am = host(loss), host(grad), host(am)
+    assert np.isposinf(loss[4]) and np.isposinf(ref_loss[4]) and loss[3] == 0
+    fin = np.isfinite(ref_loss)
+    assert relerr(loss[fin], ref_loss[fin]) < 1e-5
+    assert relerr(grad, 0.25 * ref_grad) < 1e-5
+    for b in range(B):
+        assert np.array_equal(am[b, :len_logits[b]], logits[b, :len_logits[b]].argmax(-1))
+    dense, dl = O.ctc_greedy_decode(logits, len_logits)
+    out, out_len = ops.ctc_greedy(dev(am.astype(np.int32)), dev(len_logits), V - 1)
+    assert np.array_equal(host(out_len), dl) and np.array_equal(host(out)[:, :dense.shape[1]], dense)
+    assert not host(out)[:, dense.shape[1]:].any()
+    # in-place fp32 gradient and bf16 gradient
+    lg = dev(logits)
+    _, g2, _ = ops.ctc_loss_fwd_bwd(lg, dev(len_logits), dev(labels), dev(len_labels), ops.F32, 0.25, in_place=True)
+    assert g2.data_ptr() == lg.data_ptr() and relerr(host(g2), 0.25 * ref_grad) < 1e-5
+    _, g3, _ = ops.ctc_loss_fwd_bwd(dev(logits), dev(len_logits), dev(labels), dev(len_labels), ops.BF16, 0.25)
+    assert relerr(host(g3), 0.25 * ref_grad) < 1e-2
+
+
+def test_ctc_large_vocab_rows():
+    rng = np.random.default_rng(9)
+    B, T, V, U = 2, 12, 10000, 5
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    labels = rng.integers(4, V - 1, size=(B, U)).astype(np.int32)
+    ll, lt = np.array([5, 3], np.int32), np.array([12, 8], np.int32)
+    ref_loss, ref_grad = O.ctc_loss_fwd_bwd(logits.astype(np.float64), lt, labels, ll)
+    loss, grad, _ = ops.ctc_loss_fwd_bwd(dev(logits), dev(lt), dev(labels), dev(ll), ops.F32, 1.0)
+    assert relerr(host(loss), ref_loss) < 1e-5 and relerr(host(grad), ref_grad) < 1e-5
+
+
+def test_shrink_fwd_bwd():
+    rng = np.random.default_rng(6)
+    B, T, D, V = 4, 300, 24, 9
+    logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    logits[..., V - 1] += 1.0
+    logits[3, :, V - 1] += 100.0            # utterance with zero kept frames
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    lens = np.array([300, 120, 1, 300], np.int32)
+    ref, ref_len, flag = O.shrink_fwd(x, lens, logits)
+    am = dev(logits.argmax(-1).astype(np.int32))
+    index, new_len = ops.shrink_index(am, dev(lens), V - 1)
+    assert np.array_equal(host(new_len), ref_len)
+    out = ops.shrink_fwd(dev(x), index, ref.shape[1])
+    assert np.array_equal(host(out), ref)
+    dout = rng.standard_normal(ref.shape).astype(np.float32)
+    dout *= (np.arange(ref.shape[1])[None, :, None] < ref_len[:, None, None])
+    dx = ops.shrink_bwd(dev(dout), index, T)
+    assert np.array_equal(host(dx), O.shrink_bwd(dout, flag, T))
+
+
+@pytest.mark.parametrize('V', [11, 10000])
+def test_ls_xent(V):
+    rng = np.random.default_rng(V)
+    B, L = 3, 7
+    logits = (rng.standard_normal((B, L, V)) * 3).astype(np.float32)
+    labels = rng.integers(0, V, size=(B, L)).astype(np.int32)
+    lens = np.array([7, 3, 1], np.int32)
+    ref_loss, ref_grad = O.ls_xent_fwd_bwd(logits.astype(np.float64), labels, lens, 0.9)
+    xent, grad = ops.ls_xent_fwd_bwd(dev(logits), dev(labels), dev(lens), 0.9, ops.F32, 0.5)
+    assert relerr(host(xent).sum(-1), ref_loss) < 1e-5
+    assert relerr(host(grad), 0.5 * ref_grad) < 1e-5
+    out = ops.loss_combine(xent, None, None, 0, B, L, 1.0, 0.0, 0.0, DEV)
+    assert abs(host(out)[0] - ref_loss.mean()) < 1e-5 * abs(ref_loss.mean())
+
+
+def test_mse_and_loss_combine():
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((3, 17, 24)).astype(np.float32)
+    b = rng.standard_normal((3, 17, 24)).astype(np.float32)
+    ref, dref = O.mse_fwd_bwd(b, a)
+    partial, dp = ops.mse_fwd_bwd(dev(a), dev(b), 0.05)
+    assert relerr(host(dp), 0.05 * dref) < 1e-5
+    ctc = dev(np.array([1.0, 2.0, 4.0], np.float32))
+    out = host(ops.loss_combine(None, ctc, partial, a.size, 3, 1, 0.45, 0.5, 0.05, DEV))
+    assert abs(out[3] - ref) < 1e-5 * ref and abs(out[0] - (0.5 * 7 / 3 + 0.05 * ref)) < 1e-5
+
+
+def test_embedding_and_decoder_input():
+    rng = np.random.default_rng(10)
+    B, L, D, V = 3, 6, 16, 11
+    labels = rng.integers(4, V, size=(B, L)).astype(np.int32)
+    lens = np.array([6, 2, 4], np.int32)
+    inp = host(ops.build_decoder_input(dev(labels), dev(lens), 2))
+    assert np.array_equal(inp, O.build_decoder_input(labels, lens, 2))
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    key = O.site_key(0, 2, 0)
+    e = table[inp]
+    ref, m = O.dropout_fwd(e + (e + O.timing_signal(L, D)), 0.1, key)
+    out = ops.embedding_fwd(dev(inp), dev(table), ops.F32, 0.1, key)
+    assert relerr(host(out), ref) < 1e-6
+    dout = rng.standard_normal((B, L, D)).astype(np.float32)
+    dt = torch.zeros((V, D), dtype=torch.float32, device=DEV)
+    ops.embedding_bwd(dev(inp), dev(dout), dt, 0.1, key)
+    dref = np.zeros((V, D), np.float64)
+    np.add.at(dref, inp.reshape(-1), 2.0 * (dout * m).reshape(-1, D))
+    assert relerr(host(dt), dref) < 1e-5
+
+
+def test_conv_ln_relu_and_maxpool():
+    rng = np.random.default_rng(12)
+    B, H, W, Cin, Cout = 2, 13, 10, 3, 8
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    c, ccache = O.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b, (2, 2))
+    l, lcache = O.layer_norm_fwd(c, gam.astype(np.float64), bet)
+    r = np.maximum(l, 0)
+    pooled, parg = O.maxpool3x3_fwd(r)
+    out, conv_out, mean, rstd = ops.conv2d_ln_relu_fwd(dev(x), dev(w), dev(b), dev(gam), dev(bet), (3, 3), (2, 2))
+    assert relerr(host(out), r) < 1e-5
+    po, arg = ops.maxpool3x3_fwd(out)
+    assert relerr(host(po), pooled) < 1e-5
+    dpo = rng.standard_normal(pooled.shape).astype(np.float32)
+    dr = O.maxpool3x3_bwd(dpo.astype(np.float64), parg)
+    dout = ops.maxpool3x3_bwd(dev(dpo), arg)
+    assert relerr(host(dout), dr) < 1e-5
+    dl, dg_ref, db_ref = O.layer_norm_bwd(dr * (l > 0), lcache, gam.astype(np.float64))
+    dx_ref, dw_ref, dbias_ref = O.conv2d_bwd(dl, ccache, w.astype(np.float64), (2, 2), x.shape)
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)
+    dw, dbias, dg, db = z(3, 3, Cin, Cout), z(Cout), z(Cout), z(Cout)
+    dx = ops.conv2d_ln_relu_bwd(dout, dev(x), dev(w), dev(gam), conv_out, out, mean, rstd, dw, dbias, dg, db, (3, 3), (2, 2), True)
+    for got, want in [(dx, dx_ref), (dw, dw_ref), (dbias, dbias_ref), (dg, dg_ref), (db, db_ref)]:
+        assert relerr(host(got), want) < 2e-5
+
+
+def test_adam_matches_tf_formula():
+    rng = np.random.default_rng(13)
+    n = 1003
+    p, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pad = lambda a: dev(np.concatenate([a, np.zeros(21, np.float32)]))
+    pd, gd, md, vd = pad(p), pad(g), pad(m), pad(v)
+    sh = torch.zeros(n + 21, dtype=torch.bfloat16, device=DEV)
+    import math
+    for t in (1, 2, 3):
+        lr = 1e-3
+        lr_t = lr * math.sqrt(1 - 0.98 ** t) / (1 - 0.9 ** t)
+        ops.adam_step(pd[:n], gd[:n], md[:n], vd[:n], sh[:n], lr_t, 0.9, 0.98, 1e-9, 0.5)
+        p, m, v = O.adam_step(p, 0.5 * g, m, v, lr, t)
+    assert relerr(host(pd)[:n], p) < 1e-6 and relerr(host(vd)[:n], v) < 1e-6
+    assert relerr(host(sh)[:n], p) < 1e-2

@@ -1,0 +1,147 @@
+"""CPU tests of the host side: C ABI exports, config loader, LR schedule, variable naming,
+gradient bucketing with a 2-rank gloo group."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    from neurst_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        ge.build()
+    protos = lib.parse_header()
+    text = open(lib.HEADER).read()
+    declared = set(re.findall(r'\b(neurst_\w+)\s*\(', re.sub(r'/\*.*?\*/', '', text, flags=re.S)))
+    assert declared == set(protos) and len(protos) >= 40
+    L = lib.load()
+    for name in protos:
+        assert hasattr(L, name), name
+    assert L.neurst_abi_version() == 1
+    # argument validation happens on the host before any launch: callable without a GPU
+    assert L.neurst_gemm_bias_act(0, 0, 0, 0, 0, 4, 4, 4, 4, 4, 4, 0, 1, 0, 0, 0, 0, 1, 0) == -1
+    assert b'null' in L.neurst_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from neurst_amd import lib
+    monkeypatch.setattr(lib, '_lib', None)
+    monkeypatch.setattr(lib, 'LIB_PATH', '/nonexistent/libneurst_hip.so')
+    with pytest.raises(lib.NeurstLibError):
+        lib.load()
+
+
+def test_attrdict_and_config_semantics():
+    from neurst_amd.st.layers.arguments import AttrDict, build_args
+    a = AttrDict({'x': {'y': 1}})
+    assert a.x.y == 1 and a.nope is None and a.x.nope is None
+    args = build_args(os.path.join(ROOT, 'configs', 'lut.yaml'), dim_output=10000)
+    assert args.data.dim_input == 480 and args.num_gpus == 1 and args.model.kd.num_heads == 4
+    assert args.list_batch_size[0] == int(10000 / 102) and args.list_batch_size[-1] == 1
+    assert args.model.encoder.type.__name__ == 'Transformer_Encoder' and args.Model.__name__ == 'TransformerTPE'
+    assert args.model.use_cnn_resample is None and args.model.shrink_layer is None
+    c = build_args(os.path.join(ROOT, 'configs', 'costt.yaml'), dim_output=10000)
+    assert c.model.shrink_layer is True and c.model.encoder.num_cell_units == 512
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs_template'), reason='reference templates only exist in the build container')
+@pytest.mark.parametrize('name', ['lut', 'costt'])
+def test_reference_templates_parse_unchanged_and_agree_on_hot_path_keys(name):
+    from neurst_amd.st.layers.arguments import build_args
+    ref = build_args('/root/reference/configs_template/%s.yaml' % name, dim_output=10000, overrides={'beam_size': 1})
+    own = build_args(os.path.join(ROOT, 'configs', '%s.yaml' % name), dim_output=10000)
+    for part in ('encoder', 'encoder2', 'decoder'):
+        for k in ('num_blocks', 'num_heads', 'num_cell_units', 'attention_dropout_rate', 'residual_dropout_rate'):
+            assert getattr(getattr(ref.model, part), k) == getattr(getattr(own.model, part), k)
+    for k in ('loss_type', 'shrink_layer', 'use_specAug', 'use_semantic_encoder', 'structure'):
+        assert getattr(ref.model, k) == getattr(own.model, k)
+    for k in ('warmup_steps', 'peak', 'decay_steps', 'max_len', 'num_batch_tokens'):
+        assert getattr(ref, k) == getattr(own, k)
+    assert ref.data.dim_input == own.data.dim_input == 480
+    from neurst_amd.st.models.TransformerTPE import variable_specs
+    assert variable_specs(ref) == variable_specs(own)
+
+
+def test_variable_names_and_sizes_match_survey_inventory():
+    from neurst_amd.st.layers.arguments import build_args
+    from neurst_amd.st.models.TransformerTPE import variable_specs
+    from oracle.model import TPEConfig, param_specs
+    import yaml
+    for name, total in (('lut', 120281088), ('costt', 78658560)):
+        path = os.path.join(ROOT, 'configs', name + '.yaml')
+        specs = variable_specs(build_args(path, dim_output=10000))
+        assert sum(int(np.prod(s[1])) for s in specs) == total
+        cfg = TPEConfig.from_yaml_dict(yaml.safe_load(open(path)), 10000)
+        assert [(a, tuple(b)) for a, b, _ in specs] == [(a, tuple(b)) for a, b, _ in param_specs(cfg)]
+        names = [s[0] for s in specs]
+        assert 'transformer/decoder/decoder/fully_connected/kernel' in names and 'transformer/embedding' in names
+        assert 'transformer/TPEncoder/block_0/ff_hidden/dense_1/kernel' in names
+
+
+def test_lr_schedule_matches_oracle():
+    from neurst_amd.st.models.model_tools import warmup_exponential_decay as w
+    from oracle.ops import warmup_exponential_decay as wo
+    for s in (0, 1, 999, 1000, 1001, 50000, 123456):
+        assert abs(w(s, 1000, 5e-5, 0.5, 50000) - float(wo(s, 1000, 5e-5, 0.5, 50000))) < 1e-12
+    assert w(0, 50000, 4e-4, 0.5, 50000) == 0.0
+
+
+def test_site_key_matches_oracle():
+    from neurst_amd.ops import site_key
+    from oracle.ops import site_key as so
+    for a in ((0, 0, 0), (17, 523, 99), (2 ** 31, 9000, 10 ** 6)):
+        assert site_key(*a) == so(*a)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+rank = int(sys.argv[1])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% sys.argv[2], rank=rank, world_size=2)
+from neurst_amd.st.tools.tftools.gradientTools import GradBucketer, average_gradients
+
+class P:
+    def __init__(s, name, off, size): s.name, s.offset, s.size = name, off, size
+class Store:
+    pass
+st = Store()
+sizes = [300, 50, 700, 128, 64, 1000]
+offs = np.cumsum([0] + [-(-s // 64) * 64 for s in sizes])
+st.vars = {('p%%d' %% i): P('p%%d' %% i, int(offs[i]), sizes[i]) for i in range(len(sizes))}
+st.total = int(offs[-1])
+st.grads = torch.arange(st.total, dtype=torch.float32) * (rank + 1)
+b = GradBucketer(st, bucket_bytes=4 * 512)
+assert b.world == 2 and len(b.bounds) > 2
+order = ['p5', 'p4', 'p3', 'p1', 'p2']            # backward order; p0 never reports (no gradient this step)
+for n in order:
+    b.param_done(st.vars[n])
+launched_early = sum(b.launched)
+scale = average_gradients(b)
+want = torch.arange(st.total, dtype=torch.float32) * 3
+assert scale == 0.5 and torch.equal(st.grads, want), (scale, (st.grads - want).abs().max())
+assert launched_early >= 1 and launched_early < len(b.bounds)
+# second step reuses the bucketer
+st.grads = torch.ones(st.total) * (rank + 1)
+for n in ['p0'] + order:
+    b.param_done(st.vars[n])
+assert average_gradients(b) == 0.5 and torch.equal(st.grads, torch.ones(st.total) * 3)
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_grad_bucketer_two_rank_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
