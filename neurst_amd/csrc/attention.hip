@@ -52,8 +52,16 @@ __device__ __forceinline__ void stage_transposed(T* __restrict__ St, const T* __
   for (int c = tid; c < 64 * CPR; c += 256) {
     int r = c / CPR, cc = (c % CPR) * EPC;
     auto v = load_row_chunk<T>(g + (row0 + r) * ldg, cc, dh, row0 + r < nrows, aligned);
+    if constexpr (sizeof(T) == 2) {
+      typedef unsigned short __attribute__((may_alias)) u16_alias;
+      const u32x4 a = __builtin_bit_cast(u32x4, v);
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) St[(cc + j) * LDT + r] = v[j];
+      for (int j = 0; j < EPC; ++j)
+        *reinterpret_cast<u16_alias*>(St + (cc + j) * LDT + r) = (unsigned short)((a[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) St[(cc + j) * LDT + r] = v[j];
+    }
   }
 }
 

@@ -14,8 +14,8 @@ struct CtcWs {
   int32_t* next;    // [B][Smax]  next state with the same symbol, -1 = none
   int32_t* first;   // [B][Smax]  1 if no earlier state has the same symbol
   int32_t* meta;    // [B][4]     S, active(1: run recursion), nopath, unused
-  float* logy;      // [B][T][Smax]
-  float* alpha;     // [B][T][Smax]  overwritten by the posteriors
+  double* logy;     // [B][T][Smax]  fp64: the recursion adds T of these, fp32 log-space would cost ~1e-5 in the posteriors
+  double* alpha;    // [B][T][Smax]  overwritten by the posteriors
 };
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static CtcWs carve_ws(void* ws, int64_t B, int64_t T, int64_t Smax) {
@@ -25,14 +25,14 @@ static CtcWs carve_ws(void* ws, int64_t B, int64_t T, int64_t Smax) {
   w.next = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * Smax);
   w.first = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * Smax);
   w.meta = reinterpret_cast<int32_t*>(p); p += align256(sizeof(int32_t) * B * 4);
-  w.logy = reinterpret_cast<float*>(p); p += align256(sizeof(float) * B * T * Smax);
-  w.alpha = reinterpret_cast<float*>(p);
+  w.logy = reinterpret_cast<double*>(p); p += align256(sizeof(double) * B * T * Smax);
+  w.alpha = reinterpret_cast<double*>(p);
   return w;
 }
 extern "C" int64_t neurst_ctc_workspace_bytes(int64_t B, int64_t T, int64_t Umax) {
   int64_t Smax = 2 * Umax + 1;
   return (int64_t)(3 * align256(sizeof(int32_t) * B * Smax) + align256(sizeof(int32_t) * B * 4) +
-                   2 * align256(sizeof(float) * B * T * Smax));
+                   2 * align256(sizeof(double) * B * T * Smax));
 }
 
 // ---- prep: one thread block per utterance builds l', the same-symbol chains and the feasibility flags
@@ -127,12 +127,12 @@ __global__ void __launch_bounds__(256) ctc_frame_kernel(const float* __restrict_
   const bool active = w.meta[b * 4 + 1] != 0;
   const float inv = 1.f / st.s;
   const float* src = cache ? cache : row;
-  const float lse = st.m + logf(st.s);
   if (active) {
     const int S = w.meta[b * 4 + 0];
     const int32_t* lp = w.lp + b * Smax;
-    float* ly = w.logy + bt * Smax;
-    for (int u = threadIdx.x; u < S; u += blockDim.x) ly[u] = src[lp[u]] - lse;
+    double* ly = w.logy + bt * Smax;
+    const double lse = (double)st.m + log((double)st.s);
+    for (int u = threadIdx.x; u < S; u += blockDim.x) ly[u] = (double)src[lp[u]] - lse;
   }
   // in-place safe: every element is read (from the LDS cache or by the same thread) before it is written
   for (int i = threadIdx.x; i < V; i += blockDim.x) {
@@ -141,16 +141,16 @@ __global__ void __launch_bounds__(256) ctc_frame_kernel(const float* __restrict_
   }
 }
 
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-  float m = fmaxf(a, fmaxf(b, c));
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+  double m = fmax(a, fmax(b, c));
   if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+  return m + log(exp(a - m) + exp(b - m) + exp(c - m));
 }
 
-// ---- B: alpha / beta recursion, one workgroup per utterance, one thread per state
+// ---- B: alpha / beta recursion (fp64 log space), one workgroup per utterance, one thread per state
 __global__ void ctc_alpha_beta_kernel(const int32_t* __restrict__ len_logits, CtcWs w, float* __restrict__ loss, int64_t T, int64_t Smax) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* buf = reinterpret_cast<float*>(smem);   // [2][Smax + 4], two leading / trailing -inf guards
+  double* buf = reinterpret_cast<double*>(smem);   // [2][Smax + 4], two leading / trailing -inf guards
   const int64_t b = blockIdx.x;
   const int u = threadIdx.x;
   const int S = w.meta[b * 4 + 0];
@@ -158,57 +158,58 @@ __global__ void ctc_alpha_beta_kernel(const int32_t* __restrict__ len_logits, Ct
   Tb = Tb > T ? (int)T : Tb;
   if (!w.meta[b * 4 + 1]) { if (u == 0) loss[b] = 0.f; return; }
   const int32_t* lp = w.lp + b * Smax;
-  const float* logy = w.logy + b * T * Smax;
-  float* alpha = w.alpha + b * T * Smax;
+  const double* logy = w.logy + b * T * Smax;
+  double* alpha = w.alpha + b * T * Smax;
   const int stride = (int)Smax + 4;
-  float* b0 = buf + 2;
-  float* b1 = buf + stride + 2;
-  for (int i = u; i < 2 * stride; i += blockDim.x) buf[i] = -INFINITY;
+  double* b0 = buf + 2;
+  double* b1 = buf + stride + 2;
+  const double NINF = -INFINITY;
+  for (int i = u; i < 2 * stride; i += blockDim.x) buf[i] = NINF;
   __syncthreads();
   const bool live = u < S;
   const int blank = lp[0];
   const bool skip_in = live && u >= 2 && lp[u] != blank && lp[u] != lp[u - 2];        // u-2 -> u allowed
   const bool skip_out = live && u + 2 < S && lp[u + 2] != blank && lp[u + 2] != lp[u];  // u -> u+2 allowed
-  float a = (live && u < 2) ? logy[u] : -INFINITY;
+  double a = (live && u < 2) ? logy[u] : NINF;
   if (live) { alpha[u] = a; b0[u] = a; }
   __syncthreads();
-  float* cur = b0;
-  float* nxt = b1;
+  double* cur = b0;
+  double* nxt = b1;
   for (int t = 1; t < Tb; ++t) {
     if (live) {
-      a = lse3(cur[u], cur[u - 1], skip_in ? cur[u - 2] : -INFINITY) + logy[(int64_t)t * Smax + u];
+      a = lse3(cur[u], cur[u - 1], skip_in ? cur[u - 2] : NINF) + logy[(int64_t)t * Smax + u];
       alpha[(int64_t)t * Smax + u] = a;
       nxt[u] = a;
     }
     __syncthreads();
-    float* tmp = cur; cur = nxt; nxt = tmp;
+    double* tmp = cur; cur = nxt; nxt = tmp;
   }
-  const float logp = lse3(cur[S - 1], S >= 2 ? cur[S - 2] : -INFINITY, -INFINITY);
+  const double logp = lse3(cur[S - 1], S >= 2 ? cur[S - 2] : NINF, NINF);
   __syncthreads();
   if (u == 0) {
-    loss[b] = -logp;
-    if (logp == -INFINITY) w.meta[b * 4 + 2] = 1;   // no valid path: gradient stays softmax
+    loss[b] = (float)(-logp);
+    if (logp == NINF) w.meta[b * 4 + 2] = 1;   // no valid path: gradient stays softmax
   }
-  if (logp == -INFINITY) return;
+  if (logp == NINF) return;
   // beta (emission at t excluded): beta[T-1][u] = 0 for the last two states
-  float be = (live && u >= S - 2) ? 0.f : -INFINITY;
+  double be = (live && u >= S - 2) ? 0.0 : NINF;
   if (live) {
     int64_t o = (int64_t)(Tb - 1) * Smax + u;
-    float post = expf(alpha[o] + be - logp);
+    double post = exp(alpha[o] + be - logp);
     cur[u] = be + logy[o];
     alpha[o] = post;
   }
   __syncthreads();
   for (int t = Tb - 2; t >= 0; --t) {
     if (live) {
-      be = lse3(cur[u], cur[u + 1], skip_out ? cur[u + 2] : -INFINITY);
+      be = lse3(cur[u], cur[u + 1], skip_out ? cur[u + 2] : NINF);
       int64_t o = (int64_t)t * Smax + u;
-      float post = expf(alpha[o] + be - logp);
+      double post = exp(alpha[o] + be - logp);
       nxt[u] = be + logy[o];
       alpha[o] = post;
     }
     __syncthreads();
-    float* tmp = cur; cur = nxt; nxt = tmp;
+    double* tmp = cur; cur = nxt; nxt = tmp;
   }
 }
 
@@ -224,13 +225,13 @@ __global__ void ctc_grad_fix_kernel(const int32_t* __restrict__ len_logits, CtcW
   const int32_t* lp = w.lp + b * Smax;
   const int32_t* nx = w.next + b * Smax;
   const int32_t* fi = w.first + b * Smax;
-  const float* post = w.alpha + bt * Smax;
+  const double* post = w.alpha + bt * Smax;
   TG* grow = grad + bt * V;
   for (int u = threadIdx.x; u < S; u += blockDim.x) {
     if (!fi[u]) continue;
-    float s = 0.f;
+    double s = 0.0;
     for (int k = u; k >= 0; k = nx[k]) s += post[k];
-    grow[lp[u]] = from_f32<TG>(to_f32<TG>(grow[lp[u]]) - s * grad_scale);
+    grow[lp[u]] = from_f32<TG>(to_f32<TG>(grow[lp[u]]) - (float)s * grad_scale);
   }
 }
 
@@ -255,7 +256,7 @@ extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_l
     ctc_frame_kernel<float><<<(unsigned)(B * T), 256, shm, s>>>(logits, len_logits, w, (float*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
   NEURST_CHECK_LAUNCH("ctc_frame");
   int nthr = (int)((Smax + 63) / 64 * 64);
-  ctc_alpha_beta_kernel<<<(int)B, nthr, 2 * (Smax + 4) * sizeof(float), s>>>(len_logits, w, loss, T, Smax);
+  ctc_alpha_beta_kernel<<<(int)B, nthr, 2 * (Smax + 4) * sizeof(double), s>>>(len_logits, w, loss, T, Smax);
   NEURST_CHECK_LAUNCH("ctc_alpha_beta");
   if (grad_dtype == NEURST_BF16)
     ctc_grad_fix_kernel<bf16_t><<<(unsigned)(B * T), 128, 0, s>>>(len_logits, w, (bf16_t*)grad, T, (int)V, Smax, grad_scale);

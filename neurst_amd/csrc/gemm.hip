@@ -86,15 +86,18 @@ struct Stager {
         *reinterpret_cast<typename Chunk<T>::V*>(S + row * LD + kc * EPC) = reg[i];
       }
     } else if constexpr (sizeof(T) == 2) {
+      typedef unsigned int __attribute__((may_alias)) u32_alias;
 #pragma unroll
       for (int i = 0; i < NCH; i += 2) {
         int kk, rc;
         map(i, tid, kk, rc);
+        const u32x4 a = __builtin_bit_cast(u32x4, reg[i]);       // k line kk   : 8 consecutive rows
+        const u32x4 b = __builtin_bit_cast(u32x4, reg[i + 1]);   // k line kk+1 : same rows
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
-          unsigned short lo = __builtin_bit_cast(unsigned short, reg[i][j]);
-          unsigned short hi = __builtin_bit_cast(unsigned short, reg[i + 1][j]);
-          *reinterpret_cast<unsigned int*>(S + (rc * EPC + j) * LD + kk) = (unsigned int)lo | ((unsigned int)hi << 16);
+          const unsigned int lo = (a[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+          const unsigned int hi = (b[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+          *reinterpret_cast<u32_alias*>(S + (rc * EPC + j) * LD + kk) = lo | (hi << 16);
         }
       }
     } else {
