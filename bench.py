@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: LUT train-step encoder frames/s on MI355X (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full LUT train step (a1 splice/down-sample of raw fbank resident in HBM, acoustic
+encoder, CTC head + loss, semantic encoder, decoder + label-smoothed CE, KD attention + MSE, backward,
+bucketed RCCL all-reduce when N > 1, Adam) on a synthetic batch of 32 x 1500 raw frames per GPU
+(T = 500 encoder frames), bf16 operands / fp32 accumulate, dropout 0.1, V = 10000, L = U = Lb = 40.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def lut_step_flops(B, T, L, Lb, V, d=768, din=480, nenc=4, nenc2=4, ndec=4):
+    """ALGORITHMIC forward FLOPs of one LUT step (SURVEY.md 8d formulas, 1 MAC = 2 flops); x3 for fwd+bwd."""
+    F = 4 * d
+    enc_blk = lambda rows, Tk: rows * (2 * d * 3 * d + 2 * d * d + 2 * 2 * d * F + 4 * Tk * d)
+    fwd = B * T * 2 * din * d + nenc * enc_blk(B * T, T) + B * T * 2 * d * V + nenc2 * enc_blk(B * T, T)
+    fwd += ndec * B * T * 4 * d * d                                     # decoder memory K/V projections
+    fwd += ndec * B * L * (8 * d * d + 4 * d * d + 16 * d * d + 4 * L * d + 4 * T * d) + B * L * 2 * d * V
+    fwd += B * T * 4 * d * d + B * Lb * (4 * d * d + 4 * T * d)         # KD attention
+    return fwd, 3 * fwd
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are issued on (the torch current stream)."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+
+    def wrap_gemm(self, ops):
+        orig = ops.gemm
+        timer = self
+
+        def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw):
+            if not timer.enabled:
+                return orig(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw)
+            name = 'gemm_kernel<%s,%s,%s>' % ('bf16' if A.dtype == torch.bfloat16 else 'f32',
+                                              'bf16' if C.dtype == torch.bfloat16 else 'f32',
+                                              {(False, True): 'NT', (False, False): 'NN', (True, False): 'TN'}[(bool(trans_a), bool(trans_b))])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw)
+            e1.record()
+            timer.records.setdefault(name, []).append((e0, e1, 2.0 * M * N * K))
+            return r
+        ops.gemm = gemm
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            fl = [f for _, _, f in recs]
+            out[name] = {'launches': len(recs), 'total_ms': float(sum(ms)), 'avg_us': 1e3 * float(np.mean(ms)),
+                         'flops_per_launch': float(np.mean(fl)), 'tflops': float(sum(fl) / (sum(ms) * 1e-3) / 1e12)}
+        return out
+
+
+def cpu_baseline(threads):
+    """The numpy fp32 oracle (a PORT of the reference graph - TF 1.15 cannot run here) on a bounded sample
+    of the same workload: LUT widths, B=8 x 1000 raw frames (T=334, BASELINE config 1), L=U=Lb=40, V=10000, mean of steps 2..4 of four fwd+bwd+Adam steps."""
+    import yaml
+    from oracle.model import OracleTPE, TPEConfig, init_params, train_step
+    from oracle import ops as oops
+    from neurst_amd.synthetic import make_batch
+    cfg = TPEConfig.from_yaml_dict(yaml.safe_load(open(os.path.join(ROOT, 'configs', 'lut.yaml'))), 10000).zero_dropout()
+    B, Traw, Ln = 8, 1000, 40
+    batch = make_batch(B=B, Traw=Traw, V=10000, L=Ln, U=Ln, Lb=Ln, bert_dim=768, seed=7)
+    batch['feature'], batch['len_fea'] = oops.splice_downsample_batch(batch['feature'], batch['len_fea'], 5, 3)
+    P = init_params(cfg, seed=1, dtype=np.float32)
+    M = {k: np.zeros_like(v) for k, v in P.items()}
+    V = {k: np.zeros_like(v) for k, v in P.items()}
+    model = OracleTPE(cfg, is_train=True, dropout=False)
+    nstep = 3
+    train_step(model, P, M, V, batch, 1, 50000, 4e-4, 50000)      # untimed: page in BLAS, allocate
+    t0 = time.time()
+    for i in range(nstep):
+        train_step(model, P, M, V, batch, 2 + i, 50000, 4e-4, 50000)
+    dt = (time.time() - t0) / nstep
+    T = batch['feature'].shape[1]
+    return {'value': B * T / dt, 'unit': 'encoder frames/s', 'cores': threads, 'kind': 'port',
+            'sample': 'numpy fp32 oracle (BLAS threads = cores), LUT train step at BASELINE config 1: B=%d x %d raw frames (T=%d), L=U=Lb=%d, V=10000, dropout 0; %.2f s/step over 3 timed steps' % (B, Traw, T, Ln, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--raw-frames', type=int, default=1500)
+    ap.add_argument('--config', default=os.path.join(ROOT, 'configs', 'lut.yaml'))
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--ragged', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+
+    from neurst_amd import ops
+    from neurst_amd.st.layers.arguments import build_args
+    from neurst_amd.st.models.TransformerTPE import GlobalStep
+    from neurst_amd.synthetic import make_batch
+
+    timer = KernelTimer()
+    if not a.no_kernel_timing:
+        timer.wrap_gemm(ops)
+
+    V, Ln = 10000, 40
+    args = build_args(a.config, dim_output=V, compute_dtype=a.dtype)
+    is_lut = args.model.loss_type == 'ctc_kd_ce'
+    if not is_lut:
+        Ln = 80
+    model = args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
+    B, Traw = a.batch, a.raw_frames
+    host = make_batch(B=B, Traw=Traw, V=V, L=Ln, U=40, Lb=40, bert_dim=768 if is_lut else None, seed=1234 + rank, ragged=a.ragged)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in host.items()}     # resident in HBM before the timed region
+    T = -(-Traw // args.data.downsample)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        model.train_step_async(batch)
+    barrier()
+    timer.enabled = not a.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out4 = model.train_step_async(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([dt], device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    losses = out4.cpu().numpy()
+    assert np.isfinite(losses).all(), losses
+    step_s = dt / a.steps
+    frames = B * T * world
+
+    if rank == 0:
+        d = args.model.encoder.num_cell_units
+        fwd, tot = lut_step_flops(B, T, Ln, 40, V, d=d, nenc=args.model.encoder.num_blocks, nenc2=args.model.encoder2.num_blocks,
+                                  ndec=args.model.decoder.num_blocks)
+        peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
+        kern = timer.summary()
+        roof = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'traffic': None,
+                'step_algorithmic_tflop': tot / 1e12, 'step_achieved': tot / step_s / 1e12, 'step_frac': tot / step_s / 1e12 / peak}
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]['total_ms'])
+            roof.update(kernel=dom, achieved=kern[dom]['tflops'], frac=kern[dom]['tflops'] / peak,
+                        avg_launch_us=kern[dom]['avg_us'], flops_per_launch=kern[dom]['flops_per_launch'],
+                        gemm_ms_per_step={k: v['total_ms'] / a.steps for k, v in kern.items()},
+                        gemm_tflops={k: v['tflops'] for k, v in kern.items()})
+        else:
+            roof.update(kernel='train step', achieved=roof['step_achieved'], frac=roof['step_frac'])
+        res = {
+            'metric': 'train-step encoder frames/sec', 'value': frames / step_s, 'unit': 'encoder frames/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * step_s, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'LUT train step (configs/lut.yaml = configs_template/lut.yaml dims), %d x %d raw 80-dim fbank frames per GPU '
+                                   '(T=%d), V=10000, L=U=Lb=%d, dropout 0.1, a1 splice on device' % (B, Traw, T, Ln) if is_lut else
+                                   'COSTT train step (configs/costt.yaml), %d x %d raw frames per GPU' % (B, Traw),
+                       'global_batch': B * world, 'frames_per_step': frames, 'raw_frames_per_s': 3 * frames / step_s,
+                       'parallelism': 'dp%d' % world, 'loss': float(losses[0])},
+            'roofline': roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            threads = min(os.cpu_count() or 1, 16)
+            res['cpu_baseline'] = cpu_baseline(threads)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
