@@ -118,6 +118,7 @@ template <> struct Mma<float> {
   static __device__ __forceinline__ Frag load_kstrided(const float* tile, int ld, int lane) {
     return tile[(lane >> 4) * ld + (lane & 15)];
   }
+  static __device__ __forceinline__ Frag load_tr(const float* tile, int ld, int lane) { return load_kstrided(tile, ld, lane); }
   static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -133,6 +134,18 @@ template <> struct Mma<bf16_t> {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = tile[(8 * (lane >> 4) + j) * ld + (lane & 15)];
     return f;
+  }
+  // Same fragment from a k-strided tile (element (row, k) at tile[k*ld + row], rows contiguous) with the
+  // hardware transposing read ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group g the
+  // block is k rows 8g..8g+3 (then 8g+4..8g+7) x 16 consecutive rows-of-the-operand; lane 4q+p supplies the
+  // address of block row q, columns 4p..4p+3, and lane i receives column i of the 4 block rows.
+  // tile must be an LDS pointer, 8-byte aligned, ld*2 a multiple of 8; EXEC must be full.
+  static __device__ __forceinline__ Frag load_tr(const bf16_t* tile, int ld, int lane) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_p;
+    const bf16_t* p = tile + (8 * (lane >> 4) + ((lane & 15) >> 2)) * ld + 4 * (lane & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p + 4 * ld));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
   static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);

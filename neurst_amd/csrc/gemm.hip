@@ -9,10 +9,11 @@
 
 template <typename T> struct GemmCfg;
 template <> struct GemmCfg<float> {
-  static constexpr int BK = 16, EPC = 4, LD = 20;
+  // BK x 4 B rows; LDK pads K-contiguous rows, LDT pads the 128-wide rows of k-strided tiles
+  static constexpr int BK = 16, EPC = 4, LDK = 20, LDT = 144;
 };
 template <> struct GemmCfg<bf16_t> {
-  static constexpr int BK = 64, EPC = 8, LD = 72;
+  static constexpr int BK = 64, EPC = 8, LDK = 72, LDT = 144;   // LDT: 288-B rows -> conflict-free ds_read_b64_tr_b16
 };
 constexpr int BM = 128, BN = 128, NT = 256;
 
@@ -34,81 +35,40 @@ __device__ __forceinline__ typename Chunk<T>::V load_chunk(const T* __restrict__
   return v;
 }
 
-// Stage one operand tile (128 rows x BK) into registers.  TRANS=false: memory is
-// [rows][K] (K contiguous).  TRANS=true: memory is [K][rows].
+// One operand tile (128 rows of the output dimension x BK of the reduction) staged global -> registers -> LDS in
+// the layout it has in memory: TRANS=false: memory [rows][K] -> LDS [128][LDK]; TRANS=true: memory [K][rows]
+// -> LDS [BK][LDT].  Fragments of the second kind are read with the transposing LDS read.
 template <typename T, bool TRANS>
 struct Stager {
-  static constexpr int BK = GemmCfg<T>::BK, EPC = GemmCfg<T>::EPC, LD = GemmCfg<T>::LD;
+  static constexpr int BK = GemmCfg<T>::BK, EPC = GemmCfg<T>::EPC;
+  static constexpr int LD = TRANS ? GemmCfg<T>::LDT : GemmCfg<T>::LDK;
+  static constexpr int TILE = TRANS ? BK * GemmCfg<T>::LDT : 128 * GemmCfg<T>::LDK;   // elements
   static constexpr int NCH = 128 * BK / EPC / NT;
+  static constexpr int CPR = TRANS ? 128 / EPC : BK / EPC;   // chunks per LDS row
   typename Chunk<T>::V reg[NCH];
 
   __device__ __forceinline__ void load(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R, int64_t Kend,
                                        bool aligned, int tid) {
-    if (!TRANS) {
-      constexpr int CPR = BK / EPC;  // chunks per row
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        int c = tid + i * NT;
-        int row = c / CPR, kc = c % CPR;
-        reg[i] = load_chunk<T>(base, ld, row0 + row, k0 + kc * EPC, R, Kend, aligned);
-      }
-    } else {
-      constexpr int CPK = 128 / EPC;  // chunks per k-line
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        int kk, rc;
-        map(i, tid, kk, rc);
-        reg[i] = load_chunk<T>(base, ld, k0 + kk, row0 + rc * EPC, Kend, R, aligned);
-      }
-      (void)CPK;
-    }
-  }
-  // transposed mapping: for bf16 chunks 2p and 2p+1 of a thread hold adjacent k lines
-  static __device__ __forceinline__ void map(int i, int tid, int& kk, int& rc) {
-    constexpr int CPK = 128 / EPC;
-    if (sizeof(T) == 2) {
-      int p = tid + (i >> 1) * NT;
-      kk = 2 * (p / CPK) + (i & 1);
-      rc = p % CPK;
-    } else {
-      int c = tid + i * NT;
-      kk = c / CPK;
-      rc = c % CPK;
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NT;
+      const int r = c / CPR, cc = (c % CPR) * EPC;
+      if constexpr (!TRANS) reg[i] = load_chunk<T>(base, ld, row0 + r, k0 + cc, R, Kend, aligned);
+      else reg[i] = load_chunk<T>(base, ld, k0 + r, row0 + cc, Kend, R, aligned);
     }
   }
   __device__ __forceinline__ void store(T* __restrict__ S, int tid) const {
-    if constexpr (!TRANS) {
-      constexpr int CPR = BK / EPC;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        int c = tid + i * NT;
-        int row = c / CPR, kc = c % CPR;
-        *reinterpret_cast<typename Chunk<T>::V*>(S + row * LD + kc * EPC) = reg[i];
-      }
-    } else if constexpr (sizeof(T) == 2) {
-      typedef unsigned int __attribute__((may_alias)) u32_alias;
-#pragma unroll
-      for (int i = 0; i < NCH; i += 2) {
-        int kk, rc;
-        map(i, tid, kk, rc);
-        const u32x4 a = __builtin_bit_cast(u32x4, reg[i]);       // k line kk   : 8 consecutive rows
-        const u32x4 b = __builtin_bit_cast(u32x4, reg[i + 1]);   // k line kk+1 : same rows
-#pragma unroll
-        for (int j = 0; j < EPC; ++j) {
-          const unsigned int lo = (a[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-          const unsigned int hi = (b[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-          *reinterpret_cast<u32_alias*>(S + (rc * EPC + j) * LD + kk) = lo | (hi << 16);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        int kk, rc;
-        map(i, tid, kk, rc);
-#pragma unroll
-        for (int j = 0; j < EPC; ++j) S[(rc * EPC + j) * LD + kk] = reg[i][j];
-      }
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * NT;
+      const int r = c / CPR, cc = (c % CPR) * EPC;
+      *reinterpret_cast<typename Chunk<T>::V*>(S + r * LD + cc) = reg[i];
     }
+  }
+  // fragment of 16 output rows starting at `row` for the k-step starting at `ks`
+  static __device__ __forceinline__ typename Mma<T>::Frag frag(const T* __restrict__ S, int row, int ks, int lane) {
+    if constexpr (!TRANS) return Mma<T>::load(S + row * LD + ks, LD, lane);
+    else return Mma<T>::load_tr(S + ks * LD + row, LD, lane);
   }
 };
 
@@ -121,10 +81,12 @@ struct GemmArgs {
 
 template <typename T, typename TC, bool TA, bool TB_KCONTIG>
 __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
-  // TB_KCONTIG: B stored [N][K] (trans_b = 1). Otherwise B stored [K][N] and is transposed while staging.
-  constexpr int BK = GemmCfg<T>::BK, LD = GemmCfg<T>::LD, KS = Mma<T>::KS;
-  __shared__ __attribute__((aligned(16))) T As[BM * LD];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
+  // TB_KCONTIG: B stored [N][K] (trans_b = 1); otherwise B stored [K][N].  TA: A stored [K][M].
+  constexpr int BK = GemmCfg<T>::BK, KS = Mma<T>::KS;
+  typedef Stager<T, TA> SA;
+  typedef Stager<T, !TB_KCONTIG> SB;
+  __shared__ __attribute__((aligned(16))) T As[2][SA::TILE];
+  __shared__ __attribute__((aligned(16))) T Bs[2][SB::TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
@@ -150,33 +112,42 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  Stager<T, TA> sa;
-  Stager<T, !TB_KCONTIG> sb;
+  SA sa;
+  SB sb;
+  int cur = 0;
   if (kbeg < kend) {
     sa.load(A, g.lda, m0, kbeg, g.M, kend, g.a_aligned, tid);
     sb.load(B, g.ldb, n0, kbeg, g.N, kend, g.b_aligned, tid);
+    sa.store(As[0], tid);
+    sb.store(Bs[0], tid);
   }
+  __syncthreads();
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();  // previous tile fully consumed
-    sa.store(As, tid);
-    sb.store(Bs, tid);
-    __syncthreads();
-    if (k0 + BK < kend) {  // prefetch next K-tile into registers while this one is multiplied
+    const bool more = k0 + BK < kend;
+    if (more) {   // next K-tile: global -> registers, in flight while this tile is multiplied
       sa.load(A, g.lda, m0, k0 + BK, g.M, kend, g.a_aligned, tid);
       sb.load(B, g.ldb, n0, k0 + BK, g.N, kend, g.b_aligned, tid);
     }
+    const T* Ac = As[cur];
+    const T* Bc = Bs[cur];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += KS) {
       typename Mma<T>::Frag af[4], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = Mma<T>::load(As + (wm * 64 + i * 16) * LD + ks, LD, lane);
+      for (int i = 0; i < 4; ++i) af[i] = SA::frag(Ac, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = Mma<T>::load(Bs + (wn * 64 + j * 16) * LD + ks, LD, lane);
+      for (int j = 0; j < 4; ++j) bf[j] = SB::frag(Bc, wn * 64 + j * 16, ks, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
     }
+    if (more) {   // the other buffer was last read one iteration ago (barrier below): safe to refill
+      sa.store(As[cur ^ 1], tid);
+      sb.store(Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+    cur ^= 1;
   }
   // epilogue
   TC* C = reinterpret_cast<TC*>(g.C);

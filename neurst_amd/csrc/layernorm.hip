@@ -214,15 +214,25 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, co
   }
 }
 
-// out[which][col] += sum_blk partial[blk][which][col]
-__global__ void ln_bwd_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int nblk,
-                              int C) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  int which = i / C, col = i % C;
+// out[which][col] += sum_blk partial[blk][which][col]; one block = 64 columns x 16 row lanes
+__global__ void __launch_bounds__(1024) ln_bwd_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int nblk, int C) {
+  __shared__ float sm[16][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;          // index into [2][C]
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[((int64_t)b * 2 + which) * C + col];
-  if (which == 0) dgamma[col] += s; else dbeta[col] += s;
+  if (i < 2 * C) {
+    const int which = i / C, col = i % C;
+    for (int b = rl; b < nblk; b += 16) s += partial[((int64_t)b * 2 + which) * C + col];
+  }
+  sm[rl][lane] = s;
+  __syncthreads();
+  if (rl == 0 && i < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][lane];
+    if (i < C) dgamma[i] += t; else dbeta[i - C] += t;
+  }
 }
 
 template <typename T>
@@ -264,7 +274,7 @@ static inline bool ln_vec_ok(int64_t C, int vec, const void* a, const void* b, c
 }
 extern "C" int64_t neurst_layernorm_bwd_blocks(int64_t rows) {
   int64_t g = cdiv64(rows, 4);
-  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+  return g > 512 ? 512 : (g < 1 ? 1 : g);
 }
 
 extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const float* gamma, const float* beta, void* out,
@@ -336,7 +346,7 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
 #undef BWD_VEC
   NEURST_CHECK_LAUNCH("dropout_add_layernorm_bwd");
   if (vec) {
-    ln_bwd_reduce<<<(int)cdiv64(2 * C, 256), 256, 0, s>>>(partial, dgamma, dbeta, grid, (int)C);
+    ln_bwd_reduce<<<(int)cdiv64(2 * C, 64), 1024, 0, s>>>(partial, dgamma, dbeta, grid, (int)C);
     NEURST_CHECK_LAUNCH("layernorm_bwd_reduce");
   }
   return NEURST_OK;
