@@ -36,17 +36,27 @@ __device__ __forceinline__ typename Chunk<T>::V load_chunk(const T* __restrict__
 }
 
 // One operand tile (128 rows of the output dimension x BK of the reduction) staged global -> registers -> LDS in
-// the layout it has in memory: TRANS=false: memory [rows][K] -> LDS [128][LDK]; TRANS=true: memory [K][rows]
-// -> LDS [BK][LDT].  Fragments of the second kind are read with the transposing LDS read.
+// the layout it has in memory: TRANS=false: memory [rows][K] -> LDS [128][BK]; TRANS=true: memory [K][rows]
+// -> LDS [BK][128].  Fragments of the second kind are read with the transposing LDS read.
+// bf16 tiles are unpadded and XOR-swizzled at 16-byte granularity so that both ds_read_b128 row reads
+// (128-B rows: chunk ^= row&7) and ds_read_b64_tr_b16 (256-B rows: chunk ^= ((row&3)<<2)|((row>>2)&3),
+// cdna_hip_programming.md T10 image (b)) are bank-conflict free; fp32 (parity mode) tiles are padded.
 template <typename T, bool TRANS>
 struct Stager {
   static constexpr int BK = GemmCfg<T>::BK, EPC = GemmCfg<T>::EPC;
-  static constexpr int LD = TRANS ? GemmCfg<T>::LDT : GemmCfg<T>::LDK;
-  static constexpr int TILE = TRANS ? BK * GemmCfg<T>::LDT : 128 * GemmCfg<T>::LDK;   // elements
+  static constexpr bool SWZ = sizeof(T) == 2;
+  static constexpr int LD = SWZ ? (TRANS ? 128 : BK) : (TRANS ? GemmCfg<T>::LDT : GemmCfg<T>::LDK);
+  static constexpr int TILE = (TRANS ? BK : 128) * LD;   // elements
   static constexpr int NCH = 128 * BK / EPC / NT;
   static constexpr int CPR = TRANS ? 128 / EPC : BK / EPC;   // chunks per LDS row
   typename Chunk<T>::V reg[NCH];
 
+  // element offset of 16-byte chunk `ch` of LDS row `r`
+  static __device__ __forceinline__ int off(int r, int ch) {
+    if constexpr (!SWZ) return r * LD + ch * EPC;
+    else if constexpr (!TRANS) return r * LD + ((ch ^ (r & 7)) << 3);
+    else return r * LD + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3);
+  }
   __device__ __forceinline__ void load(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R, int64_t Kend,
                                        bool aligned, int tid) {
 #pragma unroll
@@ -61,32 +71,99 @@ struct Stager {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * NT;
-      const int r = c / CPR, cc = (c % CPR) * EPC;
-      *reinterpret_cast<typename Chunk<T>::V*>(S + r * LD + cc) = reg[i];
+      *reinterpret_cast<typename Chunk<T>::V*>(S + off(c / CPR, c % CPR)) = reg[i];
     }
   }
-  // fragment of 16 output rows starting at `row` for the k-step starting at `ks`
+  // fragment of 16 output rows starting at `row` (multiple of 16) for the k-step starting at `ks`
   static __device__ __forceinline__ typename Mma<T>::Frag frag(const T* __restrict__ S, int row, int ks, int lane) {
-    if constexpr (!TRANS) return Mma<T>::load(S + row * LD + ks, LD, lane);
-    else return Mma<T>::load_tr(S + ks * LD + row, LD, lane);
+    if constexpr (!SWZ) {
+      if constexpr (!TRANS) return Mma<T>::load(S + row * LD + ks, LD, lane);
+      else return Mma<T>::load_tr(S + ks * LD + row, LD, lane);
+    } else if constexpr (!TRANS) {
+      const int r = row + (lane & 15), ch = (ks >> 3) + (lane >> 4);
+      return *reinterpret_cast<const bf16x8*>(S + off(r, ch));
+    } else {
+      typedef bf16x4 __attribute__((address_space(3))) * lds_p;
+      const int r = ks + 8 * (lane >> 4) + ((lane & 15) >> 2);
+      const int ch = (row >> 3) + ((lane >> 1) & 1), half = (lane & 1) << 2;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(S + off(r, ch) + half));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(S + off(r + 4, ch) + half));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
   }
 };
 
 struct GemmArgs {
   const void* A; const void* B; void* C; const float* bias; const void* relu_src;
   int64_t M, N, K, lda, ldb, ldc;
-  int relu, accumulate, split_k, a_aligned, b_aligned;
+  int relu, accumulate, split_k, a_aligned, b_aligned, c_vec;
   int tiles_m, tiles_n;
 };
 
-template <typename T, typename TC, bool TA, bool TB_KCONTIG>
+// direct global -> LDS copy of one full operand tile (bf16, FAST path): every lane moves 16 B with
+// global_load_lds_dwordx4; the LDS image of one wave-instruction is lane-linear, so the XOR swizzle is
+// applied to the SOURCE chunk each lane fetches (cdna_hip_programming.md 5.4 rule 21).  Rows of the
+// output dimension beyond R are clamped to a valid address: they only feed output rows/columns that the
+// epilogue never stores.  The reduction range of the tile must be fully in bounds.
+template <typename T, bool TRANS>
+__device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R,
+                                           T* __restrict__ S, int tid) {
+  typedef Stager<T, TRANS> St;
+#pragma unroll
+  for (int i = 0; i < St::NCH; ++i) {
+    const int P = tid + i * NT;                      // 16-byte chunk position in the LDS tile
+    const int r = P / St::CPR, cpos = P % St::CPR;
+    int c;                                           // source chunk that belongs at this position
+    if constexpr (!TRANS) c = cpos ^ (r & 7);
+    else c = cpos ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    const T* src;
+    if constexpr (!TRANS) {
+      int64_t gr = row0 + r;
+      gr = gr < R ? gr : R - 1;
+      src = base + gr * ld + k0 + c * 8;
+    } else {
+      int64_t gc = row0 + c * 8;
+      gc = gc + 8 <= R ? gc : 0;
+      src = base + (k0 + r) * ld + gc;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(S + (size_t)(i * NT + (tid & ~63)) * 8), 16, 0, 0);
+  }
+}
+
+template <typename T, typename SA, typename SB>
+__device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __restrict__ Bc, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+  constexpr int BK = GemmCfg<T>::BK, KS = Mma<T>::KS;
+#pragma unroll
+  for (int ks = 0; ks < BK; ks += KS) {
+    typename Mma<T>::Frag af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = SA::frag(Ac, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = SB::frag(Bc, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+  }
+}
+
+constexpr int EPI_LD = 68;                                   // fp32 row stride of the per-wave epilogue tile
+constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;               // 4 waves x 32 rows x 68 floats
+
+template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST>
 __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   // TB_KCONTIG: B stored [N][K] (trans_b = 1); otherwise B stored [K][N].  TA: A stored [K][M].
-  constexpr int BK = GemmCfg<T>::BK, KS = Mma<T>::KS;
+  // FAST (bf16, aligned operands): full K-tiles go global -> LDS directly (no VGPR staging).
+  constexpr int BK = GemmCfg<T>::BK;
   typedef Stager<T, TA> SA;
   typedef Stager<T, !TB_KCONTIG> SB;
-  __shared__ __attribute__((aligned(16))) T As[2][SA::TILE];
-  __shared__ __attribute__((aligned(16))) T Bs[2][SB::TILE];
+  constexpr int STAGE_BYTES = 2 * (SA::TILE + SB::TILE) * (int)sizeof(T);
+  constexpr int SMEM = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];   // ONE LDS object (staging ring, then epilogue tiles)
+  T* const lds = reinterpret_cast<T*>(smem);
+  auto As = [&](int b) -> T* { return lds + b * SA::TILE; };
+  auto Bs = [&](int b) -> T* { return lds + 2 * SA::TILE + b * SB::TILE; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
@@ -95,13 +172,20 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int tm = bid % g.tiles_m, tn = bid / g.tiles_m;
+  // grouped order: 8 tile-rows x all tile-columns at a time, rows fastest, so the ~64 workgroups an XCD runs
+  // together share 8 A panels and 8 B panels in its 4 MiB L2 instead of streaming 64 A panels through it
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  const int group = bid / per_group, first_m = group * GM;
+  const int gsz = g.tiles_m - first_m < GM ? g.tiles_m - first_m : GM;
+  const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   int64_t kbeg = 0, kend = g.K;
   if (g.split_k > 1) {
     int64_t per = ((g.K + g.split_k - 1) / g.split_k + BK - 1) / BK * BK;
     kbeg = per * blockIdx.z;
     kend = kbeg + per < g.K ? kbeg + per : g.K;
+    if (kbeg > kend) kbeg = kend;
   }
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
@@ -112,80 +196,167 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  SA sa;
-  SB sb;
   int cur = 0;
-  if (kbeg < kend) {
-    sa.load(A, g.lda, m0, kbeg, g.M, kend, g.a_aligned, tid);
-    sb.load(B, g.ldb, n0, kbeg, g.N, kend, g.b_aligned, tid);
-    sa.store(As[0], tid);
-    sb.store(Bs[0], tid);
-  }
-  __syncthreads();
-  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {   // next K-tile: global -> registers, in flight while this tile is multiplied
-      sa.load(A, g.lda, m0, k0 + BK, g.M, kend, g.a_aligned, tid);
-      sb.load(B, g.ldb, n0, k0 + BK, g.N, kend, g.b_aligned, tid);
+  if constexpr (FAST) {
+    const int nfull = (int)((kend - kbeg) / BK);
+    if (nfull > 0) {
+      issue_glds<T, TA>(A, g.lda, m0, kbeg, g.M, As(0), tid);
+      issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kbeg, g.N, Bs(0), tid);
     }
-    const T* Ac = As[cur];
-    const T* Bc = Bs[cur];
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += KS) {
-      typename Mma<T>::Frag af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = SA::frag(Ac, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = SB::frag(Bc, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+    for (int it = 0; it < nfull; ++it) {
+      __syncthreads();   // tile `it` has landed (vmcnt(0) precedes the barrier) and buf[cur^1] is no longer read
+      if (it + 1 < nfull) {
+        const int64_t kn = kbeg + (int64_t)(it + 1) * BK;
+        issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
+        issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
+      }
+      mma_tile<T, SA, SB>(As(cur), Bs(cur), acc, wm, wn, lane);
+      cur ^= 1;
     }
-    if (more) {   // the other buffer was last read one iteration ago (barrier below): safe to refill
-      sa.store(As[cur ^ 1], tid);
-      sb.store(Bs[cur ^ 1], tid);
+    const int64_t ktail = kbeg + (int64_t)nfull * BK;
+    if (ktail < kend) {   // partial K-tile: register staging with zero fill
+      SA sa;
+      SB sb;
+      sa.load(A, g.lda, m0, ktail, g.M, kend, true, tid);
+      sb.load(B, g.ldb, n0, ktail, g.N, kend, true, tid);
+      __syncthreads();
+      sa.store(As(cur), tid);
+      sb.store(Bs(cur), tid);
+      __syncthreads();
+      mma_tile<T, SA, SB>(As(cur), Bs(cur), acc, wm, wn, lane);
+    }
+  } else {
+    SA sa;
+    SB sb;
+    if (kbeg < kend) {
+      sa.load(A, g.lda, m0, kbeg, g.M, kend, g.a_aligned, tid);
+      sb.load(B, g.ldb, n0, kbeg, g.N, kend, g.b_aligned, tid);
+      sa.store(As(0), tid);
+      sb.store(Bs(0), tid);
     }
     __syncthreads();
-    cur ^= 1;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      if (more) {   // next K-tile: global -> registers, in flight while this tile is multiplied
+        sa.load(A, g.lda, m0, k0 + BK, g.M, kend, g.a_aligned, tid);
+        sb.load(B, g.ldb, n0, k0 + BK, g.N, kend, g.b_aligned, tid);
+      }
+      mma_tile<T, SA, SB>(As(cur), Bs(cur), acc, wm, wn, lane);
+      if (more) {   // the other buffer was last read one iteration ago (barrier below): safe to refill
+        sa.store(As(cur ^ 1), tid);
+        sb.store(Bs(cur ^ 1), tid);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
-  // epilogue
+
+  // ---- epilogue: accumulators -> per-wave fp32 LDS tile (32 rows at a time) -> row-contiguous global stores
+  __syncthreads();   // every wave is done with the staging buffers
+  float* Cs = reinterpret_cast<float*>(smem) + wave * 32 * EPI_LD;
   TC* C = reinterpret_cast<TC*>(g.C);
   const T* rs = reinterpret_cast<const T*>(g.relu_src);
   const bool add_bias = g.bias && blockIdx.z == 0;
+  const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 16 + (lane & 15);
-      if (col >= g.N) continue;
-      const float bv = add_bias ? g.bias[col] : 0.f;
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (row >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.relu) v = fmaxf(v, 0.f);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(ii * 16 + (lane >> 4) * 4 + r) * EPI_LD + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
+    // same wave reads back what it wrote: LDS operations of one wave complete in order
+    if (g.split_k > 1) {
+      // 64 consecutive fp32 per wave-instruction = 256 contiguous bytes per atomic instruction
+      if constexpr (sizeof(TC) == 4) {
+        const int64_t col = wcol0 + lane;
+        for (int rr = 0; rr < 32; ++rr) {
+          const int64_t row = wrow0 + half * 32 + rr;
+          if (row < g.M && col < g.N) {
+            float v = Cs[rr * EPI_LD + lane];
+            if (add_bias) v += g.bias[col];
+            atomicAdd(reinterpret_cast<float*>(C) + row * g.ldc + col, v);
+          }
+        }
+      }
+    } else {
+      // lane -> (row = pass*8 + lane/8, 8 consecutive columns): one 16-B (bf16) or two 16-B (fp32) stores per lane
+      const int cc = (lane & 7) * 8;
+      const int64_t col = wcol0 + cc;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rr = pass * 8 + (lane >> 3);
+        const int64_t row = wrow0 + half * 32 + rr;
+        if (row >= g.M || col >= g.N) continue;
+        float v[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + rr * EPI_LD + cc);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + rr * EPI_LD + cc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
         const int64_t off = row * g.ldc + col;
-        if (rs) v = to_f32<T>(rs[off]) > 0.f ? v : 0.f;
-        if (g.split_k > 1) {
-          if (sizeof(TC) == 4) atomicAdd(reinterpret_cast<float*>(C) + off, v);
+        const bool full = g.c_vec && col + 8 <= g.N;
+        if (add_bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (col + e < g.N) v[e] += g.bias[col + e];
+        }
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (full) {
+          if (rs) {
+            const typename Chunk<T>::V m = *reinterpret_cast<const typename Chunk<T>::V*>(rs + off);
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = to_f32<T>(m[e]) > 0.f ? v[e] : 0.f;
+            } else {
+              const typename Chunk<T>::V m2 = *reinterpret_cast<const typename Chunk<T>::V*>(rs + off + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] = to_f32<T>(m[e]) > 0.f ? v[e] : 0.f; v[4 + e] = to_f32<T>(m2[e]) > 0.f ? v[4 + e] : 0.f; }
+            }
+          }
+          if constexpr (sizeof(TC) == 2) {
+            if (g.accumulate) {
+              const bf16x8 old = *reinterpret_cast<const bf16x8*>(C + off);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(C + off) = o;
+          } else {
+            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            if (g.accumulate) {
+              o0 += *reinterpret_cast<const f32x4*>(C + off);
+              o1 += *reinterpret_cast<const f32x4*>(C + off + 4);
+            }
+            *reinterpret_cast<f32x4*>(C + off) = o0;
+            *reinterpret_cast<f32x4*>(C + off + 4) = o1;
+          }
         } else {
-          if (g.accumulate) v += to_f32<TC>(C[off]);
-          C[off] = from_f32<TC>(v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (col + e >= g.N) continue;
+            float x = v[e];
+            if (rs) x = to_f32<T>(rs[off + e]) > 0.f ? x : 0.f;
+            if (g.accumulate) x += to_f32<TC>(C[off + e]);
+            C[off + e] = from_f32<TC>(x);
+          }
         }
       }
     }
   }
 }
 
-template <typename T, typename TC>
+template <typename T, typename TC, bool FAST>
 static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.split_k);
-  if (!trans_a && trans_b) gemm_kernel<T, TC, false, true><<<grid, NT, 0, s>>>(g);
-  else if (!trans_a && !trans_b) gemm_kernel<T, TC, false, false><<<grid, NT, 0, s>>>(g);
-  else if (trans_a && !trans_b) gemm_kernel<T, TC, true, false><<<grid, NT, 0, s>>>(g);
-  else gemm_kernel<T, TC, true, true><<<grid, NT, 0, s>>>(g);
+  if (!trans_a && trans_b) gemm_kernel<T, TC, false, true, FAST><<<grid, NT, 0, s>>>(g);
+  else if (!trans_a && !trans_b) gemm_kernel<T, TC, false, false, FAST><<<grid, NT, 0, s>>>(g);
+  else if (trans_a && !trans_b) gemm_kernel<T, TC, true, false, FAST><<<grid, NT, 0, s>>>(g);
+  else gemm_kernel<T, TC, true, true, FAST><<<grid, NT, 0, s>>>(g);
   return 0;
 }
 
@@ -210,12 +381,17 @@ extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const
   int64_t tm = cdiv64(M, BM), tn = cdiv64(N, BN);
   NEURST_CHECK_ARG(tm * tn < (1ll << 30), "gemm: too many tiles");
   g.tiles_m = (int)tm; g.tiles_n = (int)tn;
+  size_t cs = dtype_size(c_dtype);
+  g.c_vec = (((uintptr_t)C & 15) == 0) && ((ldc * cs) % 16 == 0) &&
+            (!relu_src || ((((uintptr_t)relu_src & 15) == 0) && ((ldc * es) % 16 == 0)));
   hipStream_t s = as_stream(stream);
   if (ab_dtype == NEURST_BF16) {
-    if (c_dtype == NEURST_BF16) launch_gemm<bf16_t, bf16_t>(g, trans_a, trans_b, s);
-    else launch_gemm<bf16_t, float>(g, trans_a, trans_b, s);
+    // FAST: direct-to-LDS staging needs 16-byte aligned rows and whole 8-element chunks along every contiguous axis
+    const bool fast = g.a_aligned && g.b_aligned && K % 8 == 0 && (!trans_a || M % 8 == 0) && (trans_b || N % 8 == 0);
+    if (c_dtype == NEURST_BF16) { if (fast) launch_gemm<bf16_t, bf16_t, true>(g, trans_a, trans_b, s); else launch_gemm<bf16_t, bf16_t, false>(g, trans_a, trans_b, s); }
+    else { if (fast) launch_gemm<bf16_t, float, true>(g, trans_a, trans_b, s); else launch_gemm<bf16_t, float, false>(g, trans_a, trans_b, s); }
   } else {
-    launch_gemm<float, float>(g, trans_a, trans_b, s);
+    launch_gemm<float, float, false>(g, trans_a, trans_b, s);
   }
   NEURST_CHECK_LAUNCH("gemm_bias_act");
   return NEURST_OK;

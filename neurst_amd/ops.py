@@ -145,11 +145,12 @@ def colsum(x2d, out, accumulate=True):
 
 
 def pick_split_k(M, N, K, n_cu=256):
-    """wgrad-style GEMMs have few output tiles and a long reduction: split K until the grid fills the chip."""
+    """wgrad-style GEMMs have few 128x128 output tiles and a long reduction: split K until about two
+    workgroups per CU are resident (the kernel holds 2 per CU), keeping at least 1024 of K per split."""
     tiles = -(-M // 128) * -(-N // 128)
-    if tiles >= n_cu or K < 2048:
+    if tiles >= 2 * n_cu or K < 2048:
         return 1
-    return int(max(1, min(16, n_cu // tiles, K // 1024)))
+    return int(max(1, min(16, -(-2 * n_cu // tiles), K // 1024)))
 
 
 # ---- attention -------------------------------------------------------------------------

@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""Kernel-level timing (HIP events, interleaved rounds in one process) of the GEMM / attention / LN shapes
+of the LUT step.  Usage: python tools/bench_kernels.py [gemm|attn|ln|all]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neurst_amd import ops  # noqa: E402
+
+DEV = torch.device('cuda:0')
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def bench_gemm():
+    rnd = lambda *s: (torch.rand(*s, device=DEV) * 2 - 1).to(torch.bfloat16)
+    shapes = [  # name, M, N, K, ta, tb, c fp32?, split
+        ('fwd qkv   NT', 16000, 2304, 768, 0, 1, False, 1),
+        ('fwd out   NT', 16000, 768, 768, 0, 1, False, 1),
+        ('fwd ffn1  NT', 16000, 3072, 768, 0, 1, False, 1),
+        ('fwd ffn2  NT', 16000, 768, 3072, 0, 1, False, 1),
+        ('ctc head  NN', 16000, 10000, 768, 0, 0, True, 1),
+        ('dgrad ffn2 NN', 16000, 3072, 768, 0, 0, False, 1),
+        ('dgrad ffn1 NN', 16000, 768, 3072, 0, 0, False, 1),
+        ('dgrad qkv NN', 16000, 768, 2304, 0, 0, False, 1),
+        ('dgrad ctc NT', 16000, 768, 10000, 0, 1, False, 1),
+        ('wgrad ffn1 TN', 3072, 768, 16000, 1, 0, True, None),
+        ('wgrad ffn2 TN', 768, 3072, 16000, 1, 0, True, None),
+        ('wgrad qkv TN', 2304, 768, 16000, 1, 0, True, None),
+        ('wgrad out TN', 768, 768, 16000, 1, 0, True, None),
+        ('wgrad ctc TN', 768, 10000, 16000, 1, 0, True, None),
+        ('dec small NT', 1280, 768, 768, 0, 1, False, 1),
+        ('dec kv    NT', 16000, 1536, 768, 0, 1, False, 1),
+    ]
+    for name, M, N, K, ta, tb, cf32, split in shapes:
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(N, K) if tb else rnd(K, N)
+        C = torch.zeros(M, N, device=DEV, dtype=torch.float32 if cf32 else torch.bfloat16)
+        sk = ops.pick_split_k(M, N, K) if split is None else split
+        fn = lambda: ops.gemm(A, B, C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, accumulate=sk > 1 or split is None, split_k=sk)
+        med, mn = timeit(fn)
+        fl = 2.0 * M * N * K
+        print('%-16s M=%5d N=%5d K=%5d split=%2d  med %8.1f us  min %8.1f us  %7.1f TF/s' % (name, M, N, K, sk, med, mn, fl / med / 1e6))
+
+
+def bench_attn():
+    B, H, T, dh = 32, 8, 500, 96
+    d = H * dh
+    qkv = (torch.randn(B, T, 3 * d, device=DEV)).to(torch.bfloat16)
+    lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    t = qkv.view(-1)
+    for rate in (0.0, 0.1):
+        fwd = lambda: ops.mha_fwd(t, t[d:], t[2 * d:], 3 * d, 3 * d, 3 * d, B, H, T, T, dh, ops.MASK_KEYPAD, lens, rate, 123)
+        o, lse = fwd()
+        do = torch.randn_like(o)
+        dqkv = torch.empty_like(qkv)
+        dt = dqkv.view(-1)
+        bwd = lambda: ops.mha_bwd(t, t[d:], t[2 * d:], o, do, lse, dt, dt[d:], dt[2 * d:], 3 * d, 3 * d, 3 * d, 3 * d, 3 * d, 3 * d, B, H, T, T, dh,
+                                  ops.MASK_KEYPAD, lens, rate, 123)
+        fl = 4.0 * B * H * T * T * dh
+        m, _ = timeit(fwd)
+        print('attn fwd rate=%.1f  %8.1f us  %6.1f TF/s' % (rate, m, fl / m / 1e6))
+        m, _ = timeit(bwd)
+        print('attn bwd rate=%.1f  %8.1f us  %6.1f TF/s (10 B H T^2 dh flops)' % (rate, m, 2.5 * fl / m / 1e6))
+
+
+def bench_ln():
+    rows, C = 16000, 768
+    x = torch.randn(rows, C, device=DEV).to(torch.bfloat16)
+    y = torch.randn(rows, C, device=DEV).to(torch.bfloat16)
+    g = torch.ones(C, device=DEV)
+    b = torch.zeros(C, device=DEV)
+    for rate in (0.0, 0.1):
+        f = lambda: ops.dropout_add_layernorm_fwd(x, y, g, b, rate, 5)
+        m, _ = timeit(f)
+        print('ln fwd rate=%.1f %7.1f us  %6.0f GB/s (4*rows*C*2 B)' % (rate, m, 4 * rows * C * 2 / m / 1e3))
+        out, mean, rstd = f()
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        f2 = lambda: ops.dropout_add_layernorm_bwd(out, y, g, mean, rstd, dg, db, rate, 5)
+        m, _ = timeit(f2)
+        print('ln bwd rate=%.1f %7.1f us  %6.0f GB/s (%d*rows*C*2 B)' % (rate, m, (4 if rate else 3) * rows * C * 2 / m / 1e3, 4 if rate else 3))
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if what in ('gemm', 'all'):
+        bench_gemm()
+    if what in ('attn', 'all'):
+        bench_attn()
+    if what in ('ln', 'all'):
+        bench_ln()
