@@ -14,7 +14,7 @@
 
 template <typename T> struct ACfg;
 template <> struct ACfg<float> { static constexpr int EPC = 4, PAD = 4; typedef f32x4 V; static constexpr bool TR = false; };
-template <> struct ACfg<bf16_t> { static constexpr int EPC = 8, PAD = 8; typedef bf16x8 V; static constexpr bool TR = true; };
+template <> struct ACfg<bf16_t> { static constexpr int EPC = 8, PAD = 8; typedef bf16x8 V; static constexpr bool TR = false; };
 
 template <typename T> __device__ __forceinline__ float fast_exp(float x);
 template <> __device__ __forceinline__ float fast_exp<float>(float x) { return expf(x); }
@@ -84,12 +84,18 @@ __device__ __forceinline__ void load_frags_global(typename Mma<T>::Frag (&f)[DH 
   }
 }
 
-// B-operand fragment whose k index runs over the ROWS of a natural [row][col] tile (fp32) or
-// over the contiguous index of its transposed copy (bf16)
+// B-operand fragment whose k index runs over the ROWS of a natural [row][col] LDS tile: bf16 uses the
+// transposing read ds_read_b64_tr_b16, fp32 a plain strided read.  (tr / ld_tr are unused, kept for call sites.)
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::Frag load_b_rowk(const T* nat, int ld_nat, const T* tr, int ld_tr, int k0, int col0, int lane) {
-  if constexpr (ACfg<T>::TR) return Mma<T>::load(tr + col0 * ld_tr + k0, ld_tr, lane);
-  else return Mma<T>::load_kstrided(nat + k0 * ld_nat + col0, ld_nat, lane);
+  return Mma<T>::load_tr(nat + k0 * ld_nat + col0, ld_nat, lane);
+}
+
+// wave-private LDS hand-off: LDS operations of one wave execute in order, only the compiler must not reorder
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct AttnArgs {
@@ -102,10 +108,17 @@ struct AttnArgs {
   int64_t B, H, Tq, Tk;
   int dh, mask_mode;
   const int32_t* len_k;
-  uint32_t thr, key;
+  uint32_t thr, key, inner0;   // inner0 = fmix32(key): the inner hash when every flat index fits 32 bits
+  int idx32;
   float keep_scale, qscale;
   int q_aligned, k_aligned, v_aligned, o_aligned;
 };
+
+// dropout decision for weight (row, col): row_base = flat index of the row's first weight
+__device__ __forceinline__ bool attn_keep(const AttnArgs& a, uint64_t row_base, int col) {
+  if (a.idx32) return (fmix32(((uint32_t)row_base + (uint32_t)col) ^ a.inner0) >> 8) >= a.thr;
+  return dropout_keep(a.key, row_base + (uint64_t)col, a.thr);
+}
 
 __device__ __forceinline__ float group16_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
@@ -156,6 +169,10 @@ __global__ void __launch_bounds__(256) mha_fwd_kernel(AttnArgs a) {
   for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
   T* Pw = Ps + w * 16 * LDP;
   const int64_t bh = b * a.H + h;
+  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
+  uint64_t rowb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rowb[r] = (uint64_t)((bh * a.Tq + q0 + w * 16 + (lane >> 4) * 4 + r) * a.Tk);
 
   for (int64_t kv0 = 0; kv0 < kv_end; kv0 += 64) {
     __syncthreads();
@@ -172,15 +189,27 @@ __global__ void __launch_bounds__(256) mha_fwd_kernel(AttnArgs a) {
         s[nt] = Mma<T>::mma(qf[ks], Mma<T>::load(Ks + nt * 16 * LDK + ks * KS, LDK, lane), s[nt]);
     }
     float mloc[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim;   // wave-uniform: tile touches a bias or the tensor end
+    if (edge) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
-        float v = biased_score(s[nt][r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
-        s[nt][r] = v;
-        mloc[r] = fmaxf(mloc[r], v);
-      }
+        for (int r = 0; r < 4; ++r) {
+          int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
+          float v = biased_score(s[nt][r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
+          s[nt][r] = v;
+          mloc[r] = fmaxf(mloc[r], v);
+        }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[nt][r] * a.qscale;
+          s[nt][r] = v;
+          mloc[r] = fmaxf(mloc[r], v);
+        }
+    }
     float alpha[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -193,19 +222,17 @@ __global__ void __launch_bounds__(256) mha_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < DH / 16; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[i][r] *= alpha[r];
+    const int kcol = (int)kv0 + (lane & 15);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float p = (s[nt][r] == -INFINITY) ? 0.f : fast_exp<T>(s[nt][r] - m_run[r]);
+        float p = (edge && s[nt][r] == -INFINITY) ? 0.f : fast_exp<T>(s[nt][r] - m_run[r]);
         l_run[r] += p;
-        if (a.thr) {
-          int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
-          p = dropout_keep(a.key, (uint64_t)((bh * a.Tq + qi) * a.Tk + kj), a.thr) ? p * a.keep_scale : 0.f;
-        }
+        if (a.thr) p = attn_keep(a, rowb[r], kcol + nt * 16) ? p * a.keep_scale : 0.f;
         Pw[((lane >> 4) * 4 + r) * LDP + nt * 16 + (lane & 15)] = from_f32<T>(p);
       }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int ks2 = 0; ks2 < 64 / KS; ++ks2) {
       typename Mma<T>::Frag pf = Mma<T>::load(Pw + ks2 * KS, LDP, lane);
@@ -284,6 +311,11 @@ __global__ void __launch_bounds__(256) mha_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < DH / 16; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   T* Pw = Ps + w * 16 * LDP;
+  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
+  const bool q_tail = q0 + 64 > a.Tq;
+  uint64_t rowb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rowb[r] = (uint64_t)((bh * a.Tq + q0 + w * 16 + (lane >> 4) * 4 + r) * a.Tk);
 
   for (int64_t kv0 = 0; kv0 < kv_end; kv0 += 64) {
     __syncthreads();
@@ -291,6 +323,8 @@ __global__ void __launch_bounds__(256) mha_bwd_dq_kernel(AttnArgs a) {
     stage_natural<T, DH>(Vs, vg, a.ldv, kv0, a.Tk, dh, a.v_aligned, tid);
     if constexpr (ACfg<T>::TR) stage_transposed<T, DH>(Kt, kg, a.ldk, kv0, a.Tk, dh, a.k_aligned, tid);
     __syncthreads();
+    const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q_tail;
+    const int kcol = (int)kv0 + (lane & 15);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -301,15 +335,20 @@ __global__ void __launch_bounds__(256) mha_bwd_dq_kernel(AttnArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
-        float sc = biased_score(s[r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
-        float p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : fast_exp<T>(sc - lse_r[r]);
+        float p;
+        if (edge) {
+          int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
+          float sc = biased_score(s[r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
+          p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : fast_exp<T>(sc - lse_r[r]);
+        } else {
+          p = fast_exp<T>(s[r] * a.qscale - lse_r[r]);
+        }
         float dpe = dp[r];
-        if (a.thr) dpe = dropout_keep(a.key, (uint64_t)((bh * a.Tq + qi) * a.Tk + kj), a.thr) ? dpe * a.keep_scale : 0.f;
+        if (a.thr) dpe = attn_keep(a, rowb[r], kcol + nt * 16) ? dpe * a.keep_scale : 0.f;
         Pw[((lane >> 4) * 4 + r) * LDP + nt * 16 + (lane & 15)] = from_f32<T>(p * (dpe - del_r[r]));
       }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int ks2 = 0; ks2 < 64 / KS; ++ks2) {
       typename Mma<T>::Frag pf = Mma<T>::load(Pw + ks2 * KS, LDP, lane);
@@ -367,6 +406,7 @@ __global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
   int64_t q_begin = 0;
   if (a.mask_mode == NEURST_MASK_CAUSAL) q_begin = kv0;  // queries before the first key of this tile are fully masked
   if (dead) q_begin = a.Tq;
+  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
 
   for (int64_t q0 = q_begin; q0 < a.Tq; q0 += 64) {
     __syncthreads();
@@ -382,6 +422,7 @@ __global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
       del_s[tid] = qi < a.Tq ? a.delta[bh * a.Tq + qi] : 0.f;
     }
     __syncthreads();
+    const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q0 + 64 > a.Tq;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
@@ -393,14 +434,20 @@ __global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
       const int qloc = nt * 16 + (lane & 15);
       const int64_t qi = q0 + qloc;
       const float lse_q = lse_s[qloc], del_q = del_s[qloc];
+      const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int64_t kj = kv0 + w * 16 + (lane >> 4) * 4 + r;
-        float sc = biased_score(st[r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
-        float p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : fast_exp<T>(sc - lse_q);
+        const int kcol = (int)kv0 + w * 16 + (lane >> 4) * 4 + r;
+        float p;
+        if (edge) {
+          float sc = biased_score(st[r], a.qscale, qi, (int64_t)kcol, a.Tk, a.mask_mode, len);
+          p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : fast_exp<T>(sc - lse_q);
+        } else {
+          p = fast_exp<T>(st[r] * a.qscale - lse_q);
+        }
         float pd = p, dpe = dpt[r];
         if (a.thr) {
-          bool keep = dropout_keep(a.key, (uint64_t)((bh * a.Tq + qi) * a.Tk + kj), a.thr);
+          bool keep = attn_keep(a, rowb, kcol);
           pd = keep ? p * a.keep_scale : 0.f;
           dpe = keep ? dpe * a.keep_scale : 0.f;
         }
@@ -408,7 +455,7 @@ __global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
         dSw[((lane >> 4) * 4 + r) * LDP + qloc] = from_f32<T>(p * (dpe - del_q));
       }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int ks2 = 0; ks2 < 64 / KS; ++ks2) {
       typename Mma<T>::Frag pf = Mma<T>::load(Pw + ks2 * KS, LDP, lane);
@@ -477,6 +524,8 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.dh = (int)dh; a.mask_mode = mask_mode; a.len_k = len_k;
   a.thr = rate > 0.f ? rate_threshold(rate) : 0u;
   a.key = key; a.keep_scale = keep_scale(rate);
+  a.inner0 = fmix32(key);   // == fmix32(hi ^ key) with hi == 0
+  a.idx32 = (double)B * (double)H * (double)Tq * (double)Tk < 4294967296.0;
   a.qscale = 1.0f / sqrtf((float)dh);
   size_t es = dtype_size(dtype);
   auto al = [&](const void* p, int64_t ld) { return (int)((((uintptr_t)p & 15) == 0) && ((ld * es) % 16 == 0) && ((dh * es) % 16 == 0)); };

@@ -41,6 +41,16 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __
   const int lane = threadIdx.x & 63;
   const int nchunks = C / VEC;
   const float invC = 1.f / (float)C;
+  float gv[NCH][VEC], bv[NCH][VEC];   // row invariant: fetched once per wave
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + 64 * c;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      gv[c][j] = ch < nchunks ? gamma[ch * VEC + j] : 0.f;
+      bv[c][j] = ch < nchunks ? beta[ch * VEC + j] : 0.f;
+    }
+  }
   for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
     float z[NCH][VEC];
     float s = 0.f;
@@ -85,7 +95,7 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-          o[j] = keep_row ? ((z[c][j] - mu) * rs) * gamma[ch * VEC + j] + beta[ch * VEC + j] : 0.f;
+          o[j] = keep_row ? ((z[c][j] - mu) * rs) * gv[c][j] + bv[c][j] : 0.f;
         VecIO<T, VEC>::store(out + row * C + (int64_t)ch * VEC, o);
       }
     }

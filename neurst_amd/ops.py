@@ -145,12 +145,13 @@ def colsum(x2d, out, accumulate=True):
 
 
 def pick_split_k(M, N, K, n_cu=256):
-    """wgrad-style GEMMs have few 128x128 output tiles and a long reduction: split K until about two
-    workgroups per CU are resident (the kernel holds 2 per CU), keeping at least 1024 of K per split."""
+    """wgrad-style GEMMs have few 128x128 output tiles and a long reduction.  Measured on MI355X
+    (tools/sweep_splitk.py, K = 16000): the best split puts ~430 workgroups in flight, is never worth more
+    than 6 (fp32 atomic traffic grows with it) and never pays below K = 2048."""
     tiles = -(-M // 128) * -(-N // 128)
-    if tiles >= 2 * n_cu or K < 2048:
+    if K < 2048:
         return 1
-    return int(max(1, min(16, -(-2 * n_cu // tiles), K // 1024)))
+    return int(max(1, min(6, round(430.0 / tiles), K // 1024)))
 
 
 # ---- attention -------------------------------------------------------------------------
