@@ -62,6 +62,19 @@ class KernelTimer:
             timer.records.setdefault(name, []).append((e0, e1, 2.0 * M * N * K))
             return r
         ops.gemm = gemm
+        orig_w = ops.gemm_wgrad_bias
+
+        def gemm_wgrad_bias(A, B, C, opsum, which, M, N, K, lda, ldb, ldc, **kw):
+            if not timer.enabled:
+                return orig_w(A, B, C, opsum, which, M, N, K, lda, ldb, ldc, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_w(A, B, C, opsum, which, M, N, K, lda, ldb, ldc, **kw)
+            e1.record()
+            timer.records.setdefault('gemm_kernel<%s,f32,TN,+bias-grad>' % ('bf16' if A.dtype == torch.bfloat16 else 'f32'), []).append(
+                (e0, e1, 2.0 * M * N * K))
+            return r
+        ops.gemm_wgrad_bias = gemm_wgrad_bias
 
     def summary(self):
         out = {}

@@ -65,6 +65,14 @@ int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bia
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                          int trans_a, int trans_b, int ab_dtype, int c_dtype, int relu, int accumulate,
                          int split_k, void* stream);
+
+/* a8/a9 backward: weight gradient AND bias gradient of one `dense` layer (autodiff of
+ * st/models/tools/utils.py:367-398: dW = dY^T.X, db = reduce_sum(dY, rows)) in one launch.
+ * C[M,N] += A^T . B with A stored [K,M], B stored [K,N], fp32 C (split_k > 1: atomic adds);
+ * sum_operand 1: opsum[M] += sum_k A[k][m] (A is dY: '[out,in]' kernels);
+ * sum_operand 2: opsum[N] += sum_k B[k][n] (B is dY: '[in,out]' kernels).  opsum fp32, accumulated. */
+int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, float* opsum, int sum_operand, int64_t M, int64_t N,
+                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int ab_dtype, int split_k, void* stream);
 /* column sums (bias gradients): out[n] (+)= sum_m x[m,n]; out fp32. */
 int neurst_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
                   void* stream);

@@ -3,8 +3,10 @@
 //   fp32 operands -> v_mfma_f32_16x16x4_f32, exact fmaf chain     (1e-5 parity mode)
 // Replaces `dense` (st/models/tools/utils.py:367-398), tf.layers.dense and their
 // autodiff dgrad / wgrad.  128x128 block tile, 4 waves in 2x2, each wave 64x64 as 4x4
-// MFMA tiles; LDS tiles are always K-contiguous (transposed operands are transposed
-// while staging), register-prefetched one K-tile ahead.
+// MFMA tiles.  Operand tiles sit in LDS in their memory layout (k-strided tiles are read with the
+// transposing LDS read); aligned bf16 problems stream them global -> LDS directly, double-buffered.
+// The weight-gradient entry point also produces the bias gradient (a sum of one operand over the
+// reduction axis) with one extra MFMA against a fragment of ones per duty K-tile.
 #include "common.h"
 
 template <typename T> struct GemmCfg;
@@ -98,7 +100,15 @@ struct GemmArgs {
   int64_t M, N, K, lda, ldb, ldc;
   int relu, accumulate, split_k, a_aligned, b_aligned, c_vec;
   int tiles_m, tiles_n;
+  float* opsum;   // SUMOP 1: += sum_k op(A)[m][k] (length M); SUMOP 2: += sum_k op(B)[k][n] (length N)
 };
+
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag ones_frag();
+template <> __device__ __forceinline__ float ones_frag<float>() { return 1.f; }
+template <> __device__ __forceinline__ bf16x8 ones_frag<bf16_t>() {
+  const bf16_t o = (bf16_t)1.f;
+  return bf16x8{o, o, o, o, o, o, o, o};
+}
 
 // direct global -> LDS copy of one full operand tile (bf16, FAST path): every lane moves 16 B with
 // global_load_lds_dwordx4; the LDS image of one wave-instruction is lane-linear, so the XOR swizzle is
@@ -131,9 +141,12 @@ __device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t l
   }
 }
 
-template <typename T, typename SA, typename SB>
-__device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __restrict__ Bc, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+template <typename T, typename SA, typename SB, int SUMOP>
+__device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __restrict__ Bc, f32x4 (&acc)[4][4], f32x4 (&sacc)[4], bool duty,
+                                         int wm, int wn, int lane) {
   constexpr int BK = GemmCfg<T>::BK, KS = Mma<T>::KS;
+  typename Mma<T>::Frag sel = ones_frag<T>();
+  if (!duty) sel = sel - sel;
 #pragma unroll
   for (int ks = 0; ks < BK; ks += KS) {
     typename Mma<T>::Frag af[4], bf[4];
@@ -145,13 +158,22 @@ __device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+    // the sum rides on the fragments already in registers: one more MFMA per fragment against ones (duty) or
+    // zeros (not duty) - branch-free, so the register allocation of the main loop is unchanged
+    if constexpr (SUMOP == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sacc[i] = Mma<T>::mma(af[i], sel, sacc[i]);
+    } else if constexpr (SUMOP == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc[j] = Mma<T>::mma(sel, bf[j], sacc[j]);
+    }
   }
 }
 
 constexpr int EPI_LD = 68;                                   // fp32 row stride of the per-wave epilogue tile
 constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;               // 4 waves x 32 rows x 68 floats
 
-template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST>
+template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST, int SUMOP = 0>
 __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   // TB_KCONTIG: B stored [N][K] (trans_b = 1); otherwise B stored [K][N].  TA: A stored [K][M].
   // FAST (bf16, aligned operands): full K-tiles go global -> LDS directly (no VGPR staging).
@@ -195,6 +217,16 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // operand sum: the K-tiles are dealt round-robin to the blocks that share this operand panel, so every
+  // tile is summed exactly once and no block carries more than its share of the extra MFMAs
+  f32x4 sacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto duty = [&](int64_t k0) -> bool {
+    if constexpr (SUMOP == 1) return wn == 0 && (int)((k0 / BK) % g.tiles_n) == tn;
+    else if constexpr (SUMOP == 2) return wm == 0 && (int)((k0 / BK) % g.tiles_m) == tm;
+    else return false;
+  };
 
   int cur = 0;
   if constexpr (FAST) {
@@ -210,7 +242,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
         issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
         issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
       }
-      mma_tile<T, SA, SB>(As(cur), Bs(cur), acc, wm, wn, lane);
+      mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(kbeg + (int64_t)it * BK), wm, wn, lane);
       cur ^= 1;
     }
     const int64_t ktail = kbeg + (int64_t)nfull * BK;
@@ -223,7 +255,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
       sa.store(As(cur), tid);
       sb.store(Bs(cur), tid);
       __syncthreads();
-      mma_tile<T, SA, SB>(As(cur), Bs(cur), acc, wm, wn, lane);
+      mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(ktail), wm, wn, lane);
     }
   } else {
     SA sa;
@@ -241,7 +273,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
         sa.load(A, g.lda, m0, k0 + BK, g.M, kend, g.a_aligned, tid);
         sb.load(B, g.ldb, n0, k0 + BK, g.N, kend, g.b_aligned, tid);
       }
-      mma_tile<T, SA, SB>(As(cur), Bs(cur), acc, wm, wn, lane);
+      mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(k0), wm, wn, lane);
       if (more) {   // the other buffer was last read one iteration ago (barrier below): safe to refill
         sa.store(As(cur ^ 1), tid);
         sb.store(Bs(cur ^ 1), tid);
@@ -258,6 +290,25 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   const T* rs = reinterpret_cast<const T*>(g.relu_src);
   const bool add_bias = g.bias && blockIdx.z == 0;
   const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
+  if constexpr (SUMOP == 1) {   // D[m][n] = sum_k A[m][k] for every n: take column 0 (lanes 0,16,32,48)
+    if (wn == 0 && (lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = wrow0 + i * 16 + (lane >> 4) * 4 + r;
+          if (row < g.M && sacc[i][r] != 0.f) atomicAdd(g.opsum + row, sacc[i][r]);
+        }
+    }
+  } else if constexpr (SUMOP == 2) {   // D[m][n] = sum_k B[k][n] for every m: take row 0 (lanes 0..15, register 0)
+    if (wm == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = wcol0 + j * 16 + lane;
+        if (col < g.N && sacc[j][0] != 0.f) atomicAdd(g.opsum + col, sacc[j][0]);
+      }
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -360,11 +411,56 @@ static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t 
   return 0;
 }
 
+static int fill_gemm_args(GemmArgs& g, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                          int64_t ldc, int ab_dtype, int c_dtype) {
+  NEURST_CHECK_ARG(A && B && C, "gemm: null operand");
+  NEURST_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  size_t es = dtype_size(ab_dtype);
+  g.a_aligned = (((uintptr_t)A & 15) == 0) && ((lda * es) % 16 == 0);
+  g.b_aligned = (((uintptr_t)B & 15) == 0) && ((ldb * es) % 16 == 0);
+  int64_t tm = cdiv64(M, BM), tn = cdiv64(N, BN);
+  NEURST_CHECK_ARG(tm * tn < (1ll << 30), "gemm: too many tiles");
+  g.tiles_m = (int)tm; g.tiles_n = (int)tn;
+  g.c_vec = (((uintptr_t)C & 15) == 0) && ((ldc * dtype_size(c_dtype)) % 16 == 0);
+  return NEURST_OK;
+}
+
+// Weight gradient + bias gradient of one dense layer in one launch (autodiff of st/models/tools/utils.py:367-398):
+//   C[M,N] += A^T . B  with A stored [K][M], B stored [K][N] (K = rows of the layer input), fp32 C, split-K atomics;
+//   sum_operand 1: opsum[m] += sum_k A[k][m]  ('out_in' kernels: A is dY);  2: opsum[n] += sum_k B[k][n]  ('in_out': B is dY).
+template <typename T, bool FAST>
+static void launch_wgrad(const GemmArgs& g, int which, hipStream_t s) {
+  dim3 grid(g.tiles_m * g.tiles_n, 1, g.split_k);
+  if (which == 1) gemm_kernel<T, float, true, false, FAST, 1><<<grid, NT, 0, s>>>(g);
+  else gemm_kernel<T, float, true, false, FAST, 2><<<grid, NT, 0, s>>>(g);
+}
+extern "C" int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, float* opsum, int sum_operand, int64_t M, int64_t N,
+                                      int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int ab_dtype, int split_k, void* stream) {
+  NEURST_CHECK_ARG(opsum && (sum_operand == 1 || sum_operand == 2), "gemm_wgrad_bias: opsum must be given and sum_operand 1 or 2");
+  NEURST_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "gemm_wgrad_bias: leading dimension too small");
+  if (split_k < 1) split_k = 1;
+  NEURST_CHECK_ARG(split_k <= 64, "gemm: split_k too large");
+  GemmArgs g;
+  int rc = fill_gemm_args(g, A, B, C, M, N, K, lda, ldb, ldc, ab_dtype, NEURST_F32);
+  if (rc) return rc;
+  g.accumulate = 1; g.split_k = split_k; g.opsum = opsum;
+  hipStream_t s = as_stream(stream);
+  if (ab_dtype == NEURST_BF16) {
+    const bool fast = g.a_aligned && g.b_aligned && K % 8 == 0 && M % 8 == 0 && N % 8 == 0;
+    if (fast) launch_wgrad<bf16_t, true>(g, sum_operand, s); else launch_wgrad<bf16_t, false>(g, sum_operand, s);
+  } else {
+    launch_wgrad<float, false>(g, sum_operand, s);
+  }
+  NEURST_CHECK_LAUNCH("gemm_wgrad_bias");
+  return NEURST_OK;
+}
+
 extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bias, const void* relu_src, int64_t M,
                                     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
                                     int ab_dtype, int c_dtype, int relu, int accumulate, int split_k, void* stream) {
-  NEURST_CHECK_ARG(A && B && C, "gemm: null operand");
-  NEURST_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   NEURST_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm: leading dimension too small");
   NEURST_CHECK_ARG(!(ab_dtype == NEURST_F32 && c_dtype == NEURST_BF16), "gemm: fp32 operands need an fp32 result");
   if (split_k < 1) split_k = 1;
@@ -372,18 +468,12 @@ extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const
                    "gemm: split_k > 1 needs fp32 C, accumulate=1 and no activation");
   NEURST_CHECK_ARG(split_k <= 64, "gemm: split_k too large");
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias; g.relu_src = relu_src;
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  int rc = fill_gemm_args(g, A, B, C, M, N, K, lda, ldb, ldc, ab_dtype, c_dtype);
+  if (rc) return rc;
+  g.bias = bias; g.relu_src = relu_src;
   g.relu = relu; g.accumulate = accumulate; g.split_k = split_k;
-  size_t es = dtype_size(ab_dtype);
-  g.a_aligned = (((uintptr_t)A & 15) == 0) && ((lda * es) % 16 == 0);
-  g.b_aligned = (((uintptr_t)B & 15) == 0) && ((ldb * es) % 16 == 0);
-  int64_t tm = cdiv64(M, BM), tn = cdiv64(N, BN);
-  NEURST_CHECK_ARG(tm * tn < (1ll << 30), "gemm: too many tiles");
-  g.tiles_m = (int)tm; g.tiles_n = (int)tn;
-  size_t cs = dtype_size(c_dtype);
-  g.c_vec = (((uintptr_t)C & 15) == 0) && ((ldc * cs) % 16 == 0) &&
-            (!relu_src || ((((uintptr_t)relu_src & 15) == 0) && ((ldc * es) % 16 == 0)));
+  const size_t es = dtype_size(ab_dtype);
+  if (relu_src && !((((uintptr_t)relu_src & 15) == 0) && ((ldc * es) % 16 == 0))) g.c_vec = 0;
   hipStream_t s = as_stream(stream);
   if (ab_dtype == NEURST_BF16) {
     // FAST: direct-to-LDS staging needs 16-byte aligned rows and whole 8-element chunks along every contiguous axis

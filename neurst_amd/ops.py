@@ -138,6 +138,12 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias=None, relu=Fals
     return C
 
 
+def gemm_wgrad_bias(A, B, C, opsum, sum_operand, M, N, K, lda, ldb, ldc, split_k=1):
+    """C[M,N] += A^T.B (A [K,M], B [K,N]) and opsum += column sums of A (sum_operand 1) or B (2)."""
+    _chk(L().neurst_gemm_wgrad_bias(_p(A), _p(B), _p(C), _p(opsum), sum_operand, M, N, K, lda, ldb, ldc, dt_of(A), split_k, _s()),
+         'gemm_wgrad_bias')
+
+
 def colsum(x2d, out, accumulate=True):
     M, N = x2d.shape
     _chk(L().neurst_colsum(_p(x2d), _p(out), M, N, x2d.stride(0), dt_of(x2d), int(accumulate), _s()), 'colsum')

@@ -13,16 +13,23 @@ def _flat2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
-def _wgrad(dy2, x2, param, layout):
-    """param.grad += dy^T . x ('out_in' kernels) or x^T . dy ('in_out' kernels)."""
+def _wgrad(dy2, x2, param, layout, bias=None):
+    """param.grad += dy^T . x ('out_in' kernels) or x^T . dy ('in_out' kernels); bias.grad += column sums of dy
+    from the same launch."""
     M = x2.shape[0]
     n_out, n_in = dy2.shape[1], x2.shape[1]
     if layout == 'out_in':
-        ops.gemm(dy2, x2, param.grad, n_out, n_in, M, n_out, n_in, n_in, True, False, accumulate=True,
-                 split_k=ops.pick_split_k(n_out, n_in, M))
+        sk = ops.pick_split_k(n_out, n_in, M)
+        if bias is not None:
+            ops.gemm_wgrad_bias(dy2, x2, param.grad, bias.grad, 1, n_out, n_in, M, n_out, n_in, n_in, split_k=sk)
+        else:
+            ops.gemm(dy2, x2, param.grad, n_out, n_in, M, n_out, n_in, n_in, True, False, accumulate=True, split_k=sk)
     else:
-        ops.gemm(x2, dy2, param.grad, n_in, n_out, M, n_in, n_out, n_out, True, False, accumulate=True,
-                 split_k=ops.pick_split_k(n_in, n_out, M))
+        sk = ops.pick_split_k(n_in, n_out, M)
+        if bias is not None:
+            ops.gemm_wgrad_bias(x2, dy2, param.grad, bias.grad, 2, n_in, n_out, M, n_in, n_out, n_out, split_k=sk)
+        else:
+            ops.gemm(x2, dy2, param.grad, n_in, n_out, M, n_in, n_out, n_out, True, False, accumulate=True, split_k=sk)
 
 
 def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient):
@@ -48,10 +55,9 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient):
             dy2 = _flat2d(dy)
             if dy2.dtype != x2.dtype:
                 raise TypeError('gradient dtype {} does not match operand dtype {}'.format(dy2.dtype, x2.dtype))
-            _wgrad(dy2, x2, w, layout)
+            _wgrad(dy2, x2, w, layout, b)
             g.param_grad_done(w)
             if b is not None:
-                ops.colsum(dy2, b.grad, accumulate=True)
                 g.param_grad_done(b)
             if not stop_gradient:
                 have = tape.has(inputs)

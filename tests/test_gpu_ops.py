@@ -81,6 +81,22 @@ def test_gemm_splitk_and_relu_gate(dtype):
     assert relerr(host(C3), (X @ W) * (gate > 0)) < (1e-5 if dtype == 'f32' else 1e-2)
 
 
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-5), ('bf16', 1e-5)])
+@pytest.mark.parametrize('M,N,K,split', [(96, 80, 5000, 7), (768, 256, 1280, 1), (130, 257, 333, 2), (256, 384, 4096, 3)])
+def test_gemm_wgrad_with_fused_bias_gradient(dtype, tol, M, N, K, split):
+    rng = np.random.default_rng(M + K)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    A = bf16_round(rng.standard_normal((K, M)) * 0.1)
+    B = bf16_round(rng.standard_normal((K, N)) * 0.1)
+    ref = A.T.astype(np.float64) @ B
+    for which, vec, n in ((1, A, M), (2, B, N)):
+        C = torch.ones((M, N), dtype=torch.float32, device=DEV)
+        s = torch.full((n,), 2.0, dtype=torch.float32, device=DEV)
+        ops.gemm_wgrad_bias(dev(A, td), dev(B, td), C, s, which, M, N, K, M, N, N, split_k=split)
+        assert relerr(host(C), ref + 1.0) < tol
+        assert relerr(host(s), vec.astype(np.float64).sum(0) + 2.0) < 1e-5, which
+
+
 def test_colsum():
     rng = np.random.default_rng(1)
     x = rng.standard_normal((1000, 70)).astype(np.float32)
