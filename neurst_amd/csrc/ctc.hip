@@ -141,6 +141,83 @@ __global__ void __launch_bounds__(256) ctc_frame_kernel(const float* __restrict_
   }
 }
 
+
+// ---- A (register-resident rows): V <= 256*4*NV4, V % 4 == 0, 16-byte aligned rows.  Each thread keeps its
+// share of the row in registers: one HBM read, one exp per element, one vector store of the gradient base.
+template <typename TG, int NV4>
+__global__ void __launch_bounds__(256) ctc_frame_reg_kernel(const float* __restrict__ logits, const int32_t* __restrict__ len_logits,
+                                                           CtcWs w, TG* __restrict__ grad, int32_t* __restrict__ argmax, int64_t T, int V,
+                                                           int64_t Smax, float grad_scale) {
+  __shared__ RowStat red[4];
+  __shared__ float reds[4];
+  const int64_t bt = blockIdx.x, b = bt / T, t = bt % T;
+  const int nv4 = V >> 2, tid = threadIdx.x;
+  const f32x4* row4 = reinterpret_cast<const f32x4*>(logits + bt * V);
+  TG* grow = grad + bt * V;
+  auto store4 = [&](int idx, f32x4 y) {
+    if constexpr (sizeof(TG) == 4) *reinterpret_cast<f32x4*>(grow + 4 * idx) = y;
+    else *reinterpret_cast<bf16x4*>(grow + 4 * idx) = bf16x4{(bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
+  };
+  int Tb = len_logits[b];
+  Tb = Tb > T ? (int)T : Tb;
+  if (t >= Tb) {
+    for (int idx = tid; idx < nv4; idx += 256) store4(idx, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (tid == 0 && argmax) argmax[bt] = V - 1;
+    return;
+  }
+  f32x4 x[NV4];
+  RowStat st = {-INFINITY, 0.f, 0x7fffffff};
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nv4) {
+      x[i] = row4[idx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (x[i][e] > st.m) { st.m = x[i][e]; st.arg = 4 * idx + e; }
+    } else {
+      x[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(st.m, o, 64);
+    const int oa = __shfl_xor(st.arg, o, 64);
+    if (om > st.m || (om == st.m && oa < st.arg)) { st.m = om; st.arg = oa; }
+  }
+  if ((tid & 63) == 0) red[tid >> 6] = st;
+  __syncthreads();
+  st = red[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (red[i].m > st.m || (red[i].m == st.m && red[i].arg < st.arg)) st = red[i];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[i][e] = expf(x[i][e] - st.m); sum += x[i][e]; }   // exp(-inf) = 0 for the unused tail
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) reds[tid >> 6] = sum;
+  __syncthreads();
+  sum = reds[0] + reds[1] + reds[2] + reds[3];
+  if (tid == 0 && argmax) argmax[bt] = st.arg;
+  const bool active = w.meta[b * 4 + 1] != 0;
+  if (active) {
+    const int S = w.meta[b * 4 + 0];
+    const int32_t* lp = w.lp + b * Smax;
+    double* ly = w.logy + bt * Smax;
+    const double lse = (double)st.m + log((double)sum);
+    const float* row = logits + bt * V;
+    for (int u = tid; u < S; u += 256) ly[u] = (double)row[lp[u]] - lse;
+  }
+  __syncthreads();   // in-place gradient: the label columns above are read before any element is overwritten
+  const float k = active ? grad_scale / sum : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nv4) store4(idx, x[i] * k);
+  }
+}
+
 __device__ __forceinline__ double lse3(double a, double b, double c) {
   double m = fmax(a, fmax(b, c));
   if (m == -INFINITY) return -INFINITY;
@@ -250,10 +327,18 @@ extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_l
   const int use_cache = V * sizeof(float) <= 64 * 1024;
   const size_t shm = use_cache ? V * sizeof(float) : 0;
   NEURST_CHECK_ARG(use_cache || (const void*)grad != (const void*)logits, "ctc: in-place gradient needs V*4 <= 64 KiB");
-  if (grad_dtype == NEURST_BF16)
-    ctc_frame_kernel<bf16_t><<<(unsigned)(B * T), 256, shm, s>>>(logits, len_logits, w, (bf16_t*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
+  const bool vec = V % 4 == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)grad & 15) == 0 && V <= 256 * 4 * 16;
+  const unsigned nblk = (unsigned)(B * T);
+#define CTC_FRAME_REG(TG, NV4) ctc_frame_reg_kernel<TG, NV4><<<nblk, 256, 0, s>>>(logits, len_logits, w, (TG*)grad, argmax, T, (int)V, Smax, grad_scale)
+  if (vec && grad_dtype == NEURST_BF16) {
+    if (V <= 256 * 4 * 3) CTC_FRAME_REG(bf16_t, 3); else if (V <= 256 * 4 * 10) CTC_FRAME_REG(bf16_t, 10); else CTC_FRAME_REG(bf16_t, 16);
+  } else if (vec) {
+    if (V <= 256 * 4 * 3) CTC_FRAME_REG(float, 3); else if (V <= 256 * 4 * 10) CTC_FRAME_REG(float, 10); else CTC_FRAME_REG(float, 16);
+  } else if (grad_dtype == NEURST_BF16)
+    ctc_frame_kernel<bf16_t><<<nblk, 256, shm, s>>>(logits, len_logits, w, (bf16_t*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
   else
-    ctc_frame_kernel<float><<<(unsigned)(B * T), 256, shm, s>>>(logits, len_logits, w, (float*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
+    ctc_frame_kernel<float><<<nblk, 256, shm, s>>>(logits, len_logits, w, (float*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
+#undef CTC_FRAME_REG
   NEURST_CHECK_LAUNCH("ctc_frame");
   int nthr = (int)((Smax + 63) / 64 * 64);
   ctc_alpha_beta_kernel<<<(int)B, nthr, 2 * (Smax + 4) * sizeof(double), s>>>(len_logits, w, loss, T, Smax);

@@ -166,6 +166,14 @@ class TransformerTPE(Seq2SeqModel):
             g.tape.set(logits, grad)
         return loss, argmax
 
+    _ctc_stream = None
+    _ctc_pending = False
+
+    def _join_ctc_stream(self):
+        if self._ctc_pending:
+            torch.cuda.current_stream().wait_stream(self._ctc_stream)
+            self._ctc_pending = False
+
     def ctc_decode(self, argmax, len_logits):
         """tf.nn.ctc_greedy_decoder(merge_repeated=True) + sparse_to_dense (:106-125, :251-259)."""
         if self.args.ctc_beam_size and self.args.ctc_beam_size > 1:
@@ -203,17 +211,34 @@ class TransformerTPE(Seq2SeqModel):
         with G.variable_scope(self.decoder.name or 'decoder'):
             logits_am, _, len_logits_am = self.decoder_ctc(encoded=encoded_am, len_encoded=len_encoded_am)
         loss_ctc = None
+        # The CTC branch (loss, its gradient, greedy decode) only meets the rest of the step again at the loss mix
+        # and in the backward of the CTC head, so it runs on its own HIP stream beside the semantic encoder and
+        # the decoder - unless shrink_layer needs the arg-max right away.
+        side = None
+        if want_ctc_grad and not a.model.shrink_layer and logits_am.is_cuda:
+            if self._ctc_stream is None:
+                self._ctc_stream = torch.cuda.Stream(device=self.device)
+            side = self._ctc_stream
         if want_ctc_grad:
             if g.dtype == ops.F32 and self.keep_logits:
                 self.last['logits_am'] = logits_am.clone()      # the fp32 gradient overwrites the logits in place
-            loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],
-                                                len_labels=batch['len_aux_label'], grad_scale=ctc_scale)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],
+                                                        len_labels=batch['len_aux_label'], grad_scale=ctc_scale)
+                    preds_am, len_preds_am = self.ctc_decode(argmax_am, len_logits_am)
+                self._ctc_pending = True
+            else:
+                loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],
+                                                    len_labels=batch['len_aux_label'], grad_scale=ctc_scale)
         else:
             B, T, V = logits_am.shape
             argmax_am = ops.argmax_rows(logits_am.view(B * T, V)).view(B, T)
             if self.keep_logits:
                 self.last['logits_am'] = logits_am
-        preds_am, len_preds_am = self.ctc_decode(argmax_am, len_logits_am)
+        if side is None:
+            preds_am, len_preds_am = self.ctc_decode(argmax_am, len_logits_am)
         self.last['preds_am'], self.last['len_preds_am'] = preds_am, len_preds_am
         if a.model.shrink_layer:
             encoded_am, len_encoded_am = shrink_layer(encoded_am, len_encoded_am, logits_am, encoded_am.shape[-1], argmax=argmax_am)
@@ -268,6 +293,7 @@ class TransformerTPE(Seq2SeqModel):
                 encoded_feat = extract_feat(encoded, bert_feat, a)
                 mse_partial = compute_kd_loss(bert_feat, encoded_feat, a.model.kd.loss_type, grad_scale=w_kd)
                 mse_numel = encoded_feat.numel()
+            self._join_ctc_stream()
             out4 = ops.loss_combine(xent, loss_ctc, mse_partial, mse_numel, B, xent.shape[1], w_ast, w_ctc, w_kd, self.device)
             self.last.update(encoded=encoded, len_encoded=len_encoded, loss_ctc_vec=loss_ctc, xent=xent)
             tape.backward()           # `optimizer.compute_gradients(loss)` (:472)

@@ -252,15 +252,24 @@ def test_ctc_loss_grad_argmax_greedy():
     assert relerr(host(g3), 0.25 * ref_grad) < 1e-2
 
 
-def test_ctc_large_vocab_rows():
+@pytest.mark.parametrize('V', [40, 10000, 12004])
+def test_ctc_register_resident_rows(V):
+    """V % 4 == 0 takes the register-resident frame kernel (3 / 10 / 16 float4 per thread)."""
     rng = np.random.default_rng(9)
-    B, T, V, U = 2, 12, 10000, 5
+    B, T, U = 2, 12, 5
     logits = rng.standard_normal((B, T, V)).astype(np.float32)
+    logits[0, 3, 7] = logits[0, 3, 30] = 9.0          # tie: first maximum wins
     labels = rng.integers(4, V - 1, size=(B, U)).astype(np.int32)
     ll, lt = np.array([5, 3], np.int32), np.array([12, 8], np.int32)
     ref_loss, ref_grad = O.ctc_loss_fwd_bwd(logits.astype(np.float64), lt, labels, ll)
-    loss, grad, _ = ops.ctc_loss_fwd_bwd(dev(logits), dev(lt), dev(labels), dev(ll), ops.F32, 1.0)
+    loss, grad, am = ops.ctc_loss_fwd_bwd(dev(logits), dev(lt), dev(labels), dev(ll), ops.F32, 1.0)
     assert relerr(host(loss), ref_loss) < 1e-5 and relerr(host(grad), ref_grad) < 1e-5
+    assert host(am)[0, 3] == 7 and np.array_equal(host(am)[1, :8], logits[1, :8].argmax(-1)) and not host(grad)[1, 8:].any()
+    lg = dev(logits)
+    _, g2, _ = ops.ctc_loss_fwd_bwd(lg, dev(lt), dev(labels), dev(ll), ops.F32, 0.5, in_place=True)
+    assert g2.data_ptr() == lg.data_ptr() and relerr(host(g2), 0.5 * ref_grad) < 1e-5
+    _, g3, _ = ops.ctc_loss_fwd_bwd(dev(logits), dev(lt), dev(labels), dev(ll), ops.BF16, 1.0)
+    assert relerr(host(g3), ref_grad) < 1e-2
 
 
 def test_shrink_fwd_bwd():
