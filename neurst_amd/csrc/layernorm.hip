@@ -32,74 +32,118 @@ template <> struct VecIO<bf16_t, 8> {
   }
 };
 
+// row-invariant parameter chunk (VEC consecutive floats) with 16-byte loads when the pointer allows
+template <int VEC>
+__device__ __forceinline__ void load_param(const float* __restrict__ p, int ch, bool valid, bool vec_ok, float (&v)[VEC]) {
+  if (valid && vec_ok) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + ch * VEC + 4 * q);
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = valid ? p[ch * VEC + j] : 0.f;
+  }
+}
+
+// dropout decision for flat element index idx; idx32: every index of the tensor fits 32 bits, so the inner hash
+// fmix32(hi ^ key) is the launch constant `inner0`
+__device__ __forceinline__ bool ln_keep(uint32_t key, uint32_t inner0, bool idx32, int64_t idx, uint32_t thr) {
+  if (idx32) return (fmix32((uint32_t)idx ^ inner0) >> 8) >= thr;
+  return dropout_keep(key, (uint64_t)idx, thr);
+}
+
 // ------------------------------------------------------------------ forward (vector path)
-template <typename T, int VEC, int NCH>
+// One wave owns R rows at a time (all their loads are issued before the first reduction, so R rows of
+// bytes are in flight per wave); a row lives in registers as NCH 16-byte chunks per lane.
+template <typename T, int VEC, int NCH, int R>
 __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __restrict__ yz, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
                                                    float* __restrict__ rstd, int64_t rows, int C, uint32_t thr, float scale,
-                                                   uint32_t key, const int32_t* __restrict__ lens, int64_t Tn) {
+                                                   uint32_t key, uint32_t inner0, int idx32, const int32_t* __restrict__ lens, int64_t Tn) {
   const int lane = threadIdx.x & 63;
   const int nchunks = C / VEC;
   const float invC = 1.f / (float)C;
   float gv[NCH][VEC], bv[NCH][VEC];   // row invariant: fetched once per wave
+  const bool pvec = ((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int ch = lane + 64 * c;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      gv[c][j] = ch < nchunks ? gamma[ch * VEC + j] : 0.f;
-      bv[c][j] = ch < nchunks ? beta[ch * VEC + j] : 0.f;
-    }
+    load_param<VEC>(gamma, ch, ch < nchunks, pvec, gv[c]);
+    load_param<VEC>(beta, ch, ch < nchunks, pvec, bv[c]);
   }
-  for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-    float z[NCH][VEC];
-    float s = 0.f;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row0 = wave_id * R; row0 < rows; row0 += nwaves * R) {
+    float xv[R][NCH][VEC], z[R][NCH][VEC];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      int ch = lane + 64 * c;
-      if (ch < nchunks) {
-        float xv[VEC], yv[VEC];
-        int64_t off = row * C + (int64_t)ch * VEC;
-        VecIO<T, VEC>::load(x + off, xv);
-        VecIO<T, VEC>::load(yz + off, yv);
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        const int64_t off = (row0 + r) * C + (int64_t)ch * VEC;
+        if (ch < nchunks && row0 + r < rows) {
+          VecIO<T, VEC>::load(x + off, xv[r][c]);
+          VecIO<T, VEC>::load(yz + off, z[r][c]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { xv[r][c][j] = 0.f; z[r][c][j] = 0.f; }
+        }
+      }
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        const int64_t off = (row0 + r) * C + (int64_t)ch * VEC;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          float yy = yv[j];
-          if (thr) yy = dropout_keep(key, (uint64_t)(off + j), thr) ? yy * scale : 0.f;
+          float yy = z[r][c][j];
+          if (thr) yy = ln_keep(key, inner0, idx32, off + j, thr) ? yy * scale : 0.f;
           // the residual sum is rounded to the activation type, as it would be if stored
-          z[c][j] = to_f32<T>(from_f32<T>(xv[j] + yy));
-          s += z[c][j];
+          z[r][c][j] = to_f32<T>(from_f32<T>(xv[r][c][j] + yy));
+          s[r] += z[r][c][j];
         }
-        VecIO<T, VEC>::store(yz + off, z[c]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) z[c][j] = 0.f;
+        if (ch < nchunks && row0 + r < rows) VecIO<T, VEC>::store(yz + off, z[r][c]);
       }
     }
-    const float mu = wave_sum(s) * invC;
-    float q = 0.f;
+    float mu[R], rs[R];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (lane + 64 * c < nchunks) {
+    for (int r = 0; r < R; ++r) mu[r] = wave_sum(s[r]) * invC;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { float d = z[c][j] - mu; q += d * d; }
-      }
-    const float var = wave_sum(q) * invC;
-    const float rs = 1.0f / sqrtf(var + LN_EPS);
-    bool keep_row = true;
-    if (lens) keep_row = (row % Tn) < lens[row / Tn];
+    for (int r = 0; r < R; ++r) {
+      float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      int ch = lane + 64 * c;
-      if (ch < nchunks) {
-        float o[VEC];
+      for (int c = 0; c < NCH; ++c)
+        if (lane + 64 * c < nchunks) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          o[j] = keep_row ? ((z[c][j] - mu) * rs) * gv[c][j] + bv[c][j] : 0.f;
-        VecIO<T, VEC>::store(out + row * C + (int64_t)ch * VEC, o);
-      }
+          for (int j = 0; j < VEC; ++j) { float d = z[r][c][j] - mu[r]; q += d * d; }
+        }
+      s[r] = q;
     }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rs[r] = 1.0f / sqrtf(wave_sum(s[r]) * invC + LN_EPS);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = row0 + r;
+      if (row >= rows) break;
+      bool keep_row = true;
+      if (lens) keep_row = (row % Tn) < lens[row / Tn];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) {
+          float o[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            o[j] = keep_row ? ((z[r][c][j] - mu[r]) * rs[r]) * gv[c][j] + bv[c][j] : 0.f;
+          VecIO<T, VEC>::store(out + row * C + (int64_t)ch * VEC, o);
+        }
+      }
+      if (lane == 0) { mean[row] = mu[r]; rstd[row] = rs[r]; }
+    }
   }
 }
 
@@ -140,21 +184,21 @@ template <typename T, int VEC, int NCH>
 __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ gamma,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dz,
                                                    T* __restrict__ dy, float* __restrict__ partial, int64_t rows, int C, uint32_t thr,
-                                                   float scale, uint32_t key, const int32_t* __restrict__ lens, int64_t Tn) {
+                                                   float scale, uint32_t key, uint32_t inner0, int idx32,
+                                                   const int32_t* __restrict__ lens, int64_t Tn) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sm = reinterpret_cast<float*>(smem_raw);  // [2][4][C]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunks = C / VEC;
   const float invC = 1.f / (float)C;
   float dgam[NCH][VEC], dbet[NCH][VEC], gv[NCH][VEC];
+  const bool pvec = (((uintptr_t)gamma) & 15) == 0;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     int ch = lane + 64 * c;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      dgam[c][j] = 0.f; dbet[c][j] = 0.f;
-      gv[c][j] = ch < nchunks ? gamma[ch * VEC + j] : 0.f;
-    }
+    for (int j = 0; j < VEC; ++j) { dgam[c][j] = 0.f; dbet[c][j] = 0.f; }
+    load_param<VEC>(gamma, ch, ch < nchunks, pvec, gv[c]);
   }
   for (int64_t row = blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
     bool keep_row = true;
@@ -197,7 +241,7 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, co
         VecIO<T, VEC>::store(dz + off, o);
         if (thr) {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) o[j] = dropout_keep(key, (uint64_t)(off + j), thr) ? o[j] * scale : 0.f;
+          for (int j = 0; j < VEC; ++j) o[j] = ln_keep(key, inner0, idx32, off + j, thr) ? o[j] * scale : 0.f;
           VecIO<T, VEC>::store(dy + off, o);
         }
       }
@@ -297,9 +341,13 @@ extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const f
   int64_t g = cdiv64(rows, 4);
   int grid = (int)(g > 4096 ? 4096 : g);
   hipStream_t s = as_stream(stream);
-#define FWD_VEC(TT, VEC, NCH)                                                                                            \
-  ln_fwd_vec<TT, VEC, NCH><<<grid, 256, 0, s>>>((const TT*)x, (TT*)yz, gamma, beta, (TT*)out, mean, rstd, rows, (int)C, \
-                                                thr, sc, key, lens, T)
+  const uint32_t inner0 = fmix32(key);
+  const int idx32 = (double)rows * (double)C < 4294967296.0;
+  // persistent waves: at most 1024 workgroups, each wave walks rows with stride (measured best: 1 row in flight per wave)
+  const int gv_ = (int)(g > 1024 ? 1024 : g);
+#define FWD_VEC(TT, VEC, NCH)                                                                                              \
+  ln_fwd_vec<TT, VEC, NCH, 1><<<gv_, 256, 0, s>>>((const TT*)x, (TT*)yz, gamma, beta, (TT*)out, mean, rstd, rows, (int)C, \
+                                                  thr, sc, key, inner0, idx32, lens, T)
 #define FWD_DISPATCH(TT, VEC)                                         \
   switch (ln_nch(C, VEC)) {                                           \
     case 1: FWD_VEC(TT, VEC, 1); break;                               \
@@ -334,9 +382,11 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   hipStream_t s = as_stream(stream);
   size_t shmem = (size_t)8 * C * sizeof(float);
   bool vec = false;
+  const uint32_t inner0 = fmix32(key);
+  const int idx32 = (double)rows * (double)C < 4294967296.0;
 #define BWD_VEC(TT, VEC, NCH)                                                                                                \
   ln_bwd_vec<TT, VEC, NCH><<<grid, 256, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, partial, \
-                                                    rows, (int)C, thr, sc, key, lens, T)
+                                                    rows, (int)C, thr, sc, key, inner0, idx32, lens, T)
 #define BWD_DISPATCH(TT, VEC)                                         \
   switch (ln_nch(C, VEC)) {                                           \
     case 1: BWD_VEC(TT, VEC, 1); break;                               \
