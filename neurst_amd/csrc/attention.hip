@@ -5,20 +5,33 @@
 // dropout on the weights, weights.v).
 //
 // Layout: one workgroup = 4 waves = 64 query rows (forward, dQ) or 64 keys (dK/dV);
-// K/V (or Q/dO) tiles of 64 rows are staged through LDS; every product runs on
-// 16x16 MFMA tiles (bf16: 16x16x32, fp32 parity mode: 16x16x4); softmax statistics are
-// wavefront shuffles over the 16 lanes that share a row.
+// K/V (or Q/dO) tiles of 64 rows are staged through LDS in their natural [row][dh] layout; every
+// product runs on 16x16 MFMA tiles (bf16: 16x16x32, fp32 parity mode: 16x16x4).  Scores are computed
+// transposed so that each lane owns one query (or key): probabilities and dS stay in registers and feed
+// the second product directly (no LDS round trip), row statistics need two shuffles per tile.
 #include "common.h"
 
 #define NEG_BIAS (-1e9f)
+#ifndef DKV_PREFETCH
+#define DKV_PREFETCH 0
+#endif
+#ifndef FWD_WPE
+#define FWD_WPE 3
+#endif
+#ifndef DQ_WPE
+#define DQ_WPE 3
+#endif
+#ifndef DKV_WPE
+#define DKV_WPE 3
+#endif
+#define ATT_OCC(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// stops the instruction scheduler from hoisting every LDS fragment read of a phase to its start (which costs
+// 100+ registers and the occupancy with them); other waves hide the LDS latency instead
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <typename T> struct ACfg;
-template <> struct ACfg<float> { static constexpr int EPC = 4, PAD = 4; typedef f32x4 V; static constexpr bool TR = false; };
-template <> struct ACfg<bf16_t> { static constexpr int EPC = 8, PAD = 8; typedef bf16x8 V; static constexpr bool TR = false; };
-
-template <typename T> __device__ __forceinline__ float fast_exp(float x);
-template <> __device__ __forceinline__ float fast_exp<float>(float x) { return expf(x); }
-template <> __device__ __forceinline__ float fast_exp<bf16_t>(float x) { return __expf(x); }
+template <> struct ACfg<float> { static constexpr int EPC = 4, PAD = 4; typedef f32x4 V; };
+template <> struct ACfg<bf16_t> { static constexpr int EPC = 8, PAD = 16; typedef bf16x8 V; };   // (DH + 16) / 2 dwords = 8 mod 16: conflict-free b128 and tr reads
 
 template <typename T>
 __device__ __forceinline__ typename ACfg<T>::V load_row_chunk(const T* __restrict__ row, int c, int dh, bool valid, bool aligned) {
@@ -44,26 +57,35 @@ __device__ __forceinline__ void stage_natural(T* __restrict__ S, const T* __rest
     *reinterpret_cast<typename ACfg<T>::V*>(S + r * LD + cc) = v;
   }
 }
-// St[c][r] = g[(row0+r)*ldg + c]   (row index becomes the contiguous one)
-template <typename T, int DH>
-__device__ __forceinline__ void stage_transposed(T* __restrict__ St, const T* __restrict__ g, int64_t ldg, int64_t row0, int64_t nrows,
-                                                 int dh, bool aligned, int tid) {
-  constexpr int EPC = ACfg<T>::EPC, LDT = 64 + ACfg<T>::PAD, CPR = DH / EPC;
-  for (int c = tid; c < 64 * CPR; c += 256) {
-    int r = c / CPR, cc = (c % CPR) * EPC;
-    auto v = load_row_chunk<T>(g + (row0 + r) * ldg, cc, dh, row0 + r < nrows, aligned);
-    if constexpr (sizeof(T) == 2) {
-      typedef unsigned short __attribute__((may_alias)) u16_alias;
-      const u32x4 a = __builtin_bit_cast(u32x4, v);
+// The same tile in two halves - global -> registers, registers -> LDS - so that the loads of the NEXT tile are in
+// flight while the current one is multiplied.  FULL (dh == DH, 16-byte aligned rows): branch-free 16-byte loads, rows
+// beyond the tensor are clamped and zeroed by a select.
+template <typename T, int DH, bool FULL>
+struct TileRegs {
+  static constexpr int EPC = ACfg<T>::EPC, LD = DH + ACfg<T>::PAD, CPR = DH / EPC, NCH = 64 * CPR / 256;
+  typename ACfg<T>::V reg[NCH];
+  __device__ __forceinline__ void load(const T* __restrict__ g, int64_t ldg, int64_t row0, int64_t nrows, int dh, bool aligned, int tid) {
 #pragma unroll
-      for (int j = 0; j < EPC; ++j)
-        *reinterpret_cast<u16_alias*>(St + (cc + j) * LDT + r) = (unsigned short)((a[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-    } else {
-#pragma unroll
-      for (int j = 0; j < EPC; ++j) St[(cc + j) * LDT + r] = v[j];
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 256, r = c / CPR, cc = (c % CPR) * EPC;
+      if constexpr (FULL) {
+        const int64_t row = row0 + r;
+        const typename ACfg<T>::V v = *reinterpret_cast<const typename ACfg<T>::V*>(g + (row < nrows ? row : nrows - 1) * ldg + cc);
+        const typename ACfg<T>::V zero = {};
+        reg[i] = row < nrows ? v : zero;
+      } else {
+        reg[i] = load_row_chunk<T>(g + (row0 + r) * ldg, cc, dh, row0 + r < nrows, aligned);
+      }
     }
   }
-}
+  __device__ __forceinline__ void store(T* __restrict__ S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<typename ACfg<T>::V*>(S + (c / CPR) * LD + (c % CPR) * EPC) = reg[i];
+    }
+  }
+};
 
 // A-operand fragments of 16 rows straight from global memory: frag[ks] covers k in [ks*KS, ks*KS+KS)
 template <typename T, int DH>
@@ -84,19 +106,57 @@ __device__ __forceinline__ void load_frags_global(typename Mma<T>::Frag (&f)[DH 
   }
 }
 
-// B-operand fragment whose k index runs over the ROWS of a natural [row][col] LDS tile: bf16 uses the
-// transposing read ds_read_b64_tr_b16, fp32 a plain strided read.  (tr / ld_tr are unused, kept for call sites.)
-template <typename T>
-__device__ __forceinline__ typename Mma<T>::Frag load_b_rowk(const T* nat, int ld_nat, const T* tr, int ld_tr, int k0, int col0, int lane) {
-  return Mma<T>::load_tr(nat + k0 * ld_nat + col0, ld_nat, lane);
-}
+// ---- register-resident probabilities -------------------------------------------------------------------
+// Scores are produced TRANSPOSED so that the probabilities never visit LDS.  A 16x16 accumulator tile holds,
+// in lane l, column (l & 15) and rows 4(l >> 4) + r.  With the contraction index of the SECOND product on the
+// accumulator rows, the four registers of nt-tile pairs are exactly a B-operand fragment of that product once
+// its k slots are permuted: slot (g = l >> 4, j) of k-step `step` stands for tile row
+//     bf16 (k = 32 per step): 32 step + 16 (j >> 2) + 4 g + (j & 3)      fp32 (k = 4): 16 (step >> 2) + 4 g + (step & 3)
+// and the other operand (rows of a natural [row][col] LDS tile, read transposed) uses the same permutation.
+template <typename T> struct RegP;
+template <> struct RegP<float> {
+  static constexpr int NSTEP = 16;
+  static __device__ __forceinline__ float bfrag(const f32x4 (&p)[4], int step) { return p[step >> 2][step & 3]; }
+  // same fragment from the two nt tiles of one half (steps NSTEP/2 * half + ls)
+  static __device__ __forceinline__ float bfrag_half(const f32x4 (&p)[2], int ls) { return p[ls >> 2][ls & 3]; }
+  // A fragment: element (row = col0 + (l & 15), slot) = tile[tile_row(slot)][col0 + (l & 15)]
+  static __device__ __forceinline__ float afrag_tr(const float* tile, int ld, int step, int col0, int lane) {
+    return tile[(16 * (step >> 2) + 4 * (lane >> 4) + (step & 3)) * ld + col0 + (lane & 15)];
+  }
+};
+template <> struct RegP<bf16_t> {
+  static constexpr int NSTEP = 2;
+  static __device__ __forceinline__ bf16x8 bfrag(const f32x4 (&p)[4], int step) {
+    const f32x4 a = p[2 * step], b = p[2 * step + 1];
+    return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+  }
+  static __device__ __forceinline__ bf16x8 bfrag_half(const f32x4 (&p)[2], int) {
+    const f32x4 a = p[0], b = p[1];
+    return bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+  }
+  // two ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p addresses tile row (base + q), columns 4p..4p+3 and
+  // lane i receives column i of those 4 rows (EXEC must be full; 8-byte aligned)
+  static __device__ __forceinline__ bf16x8 afrag_tr(const bf16_t* tile, int ld, int step, int col0, int lane) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_p;
+    const bf16_t* p = tile + (32 * step + 4 * (lane >> 4) + ((lane & 15) >> 2)) * ld + col0 + 4 * (lane & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p + 16 * ld));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
 
-// wave-private LDS hand-off: LDS operations of one wave execute in order, only the compiler must not reorder
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// softmax arithmetic: fp32 = exact expf in natural units (parity mode); bf16 = base-2 with log2(e) folded into the scale
+template <typename T> struct SM;
+template <> struct SM<float> {
+  static __device__ __forceinline__ float unit() { return 1.f; }
+  static __device__ __forceinline__ float ex(float x) { return expf(x); }
+  static __device__ __forceinline__ float lse(float m, float l) { return m + logf(l); }
+};
+template <> struct SM<bf16_t> {
+  static __device__ __forceinline__ float unit() { return 1.4426950408889634f; }
+  static __device__ __forceinline__ float ex(float x) { return __builtin_amdgcn_exp2f(x); }
+  static __device__ __forceinline__ float lse(float m, float l) { return (m + __log2f(l)) * 0.6931471805599453f; }
+};
 
 struct AttnArgs {
   const void *q, *k, *v, *o, *d_o;
@@ -112,6 +172,7 @@ struct AttnArgs {
   int idx32;
   float keep_scale, qscale;
   int q_aligned, k_aligned, v_aligned, o_aligned;
+  int out_vec, dq_vec, dk_vec, dv_vec;   // 4 consecutive head columns may be stored as one vector
 };
 
 // dropout decision for weight (row, col): row_base = flat index of the row's first weight
@@ -120,34 +181,59 @@ __device__ __forceinline__ bool attn_keep(const AttnArgs& a, uint64_t row_base, 
   return dropout_keep(a.key, row_base + (uint64_t)col, a.thr);
 }
 
-__device__ __forceinline__ float group16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
-  return v;
+// keep decisions of the 16 weights a lane owns in one 64-wide tile, as a bit mask (bit nt*4 + r <-> flat index
+// base + col0 + nt*stride_nt + r*stride_r).  Kept behind an opaque barrier so that the hash arithmetic is not
+// interleaved with (and does not hold registers across) the MFMA phases.
+__device__ __forceinline__ uint32_t keep_bits16(const AttnArgs& a, uint64_t base, int col0, int stride_nt, int stride_r) {
+  uint32_t m = 0xFFFFu;
+  if (a.thr) {
+    m = 0;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m |= (attn_keep(a, base, col0 + nt * stride_nt + r * stride_r) ? 1u : 0u) << (nt * 4 + r);
+  }
+  asm volatile("" : "+v"(m));
+  return m;
 }
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+
+__device__ __forceinline__ float quad_groups_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+__device__ __forceinline__ float quad_groups_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
-// score of (query qi, key kj) after scaling and the reference's additive biases; -inf outside the tensor
-__device__ __forceinline__ float biased_score(float raw, float qscale, int64_t qi, int64_t kj, int64_t Tk, int mask_mode, int len) {
+// scaled score of (query qi, key kj) with the reference's additive biases (in units of `unit`); -inf outside the tensor
+__device__ __forceinline__ float biased_score(float raw, float c, float unit, int64_t qi, int64_t kj, int64_t Tk, int mask_mode, int len) {
   if (kj >= Tk) return -INFINITY;
-  float s = raw * qscale;
-  if (mask_mode == NEURST_MASK_KEYPAD) { if (kj >= len) s += NEG_BIAS; }
-  else if (mask_mode == NEURST_MASK_CAUSAL) { if (kj > qi) s += NEG_BIAS; }
+  float s = raw * c;
+  if (mask_mode == NEURST_MASK_KEYPAD) { if (kj >= len) s += NEG_BIAS * unit; }
+  else if (mask_mode == NEURST_MASK_CAUSAL) { if (kj > qi) s += NEG_BIAS * unit; }
   return s;
 }
 
+// 4 consecutive head columns c0..c0+3 of one row
+template <typename T>
+__device__ __forceinline__ void store4(T* __restrict__ row, int c0, int dh, f32x4 v, bool vec) {
+  if (vec && c0 + 4 <= dh) {
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(row + c0) = v;
+    else *reinterpret_cast<bf16x4*>(row + c0) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (c0 + r < dh) row[c0 + r] = from_f32<T>(v[r]);
+  }
+}
+
 // ================================================================== forward
-template <typename T, int DH>
-__global__ void __launch_bounds__(256) mha_fwd_kernel(AttnArgs a) {
-  constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD, LDT = 64 + ACfg<T>::PAD, LDP = 64 + ACfg<T>::PAD;
+// workgroup = 64 queries (16 per wave); lane l works for query (l & 15); S^T = K.Q^T, O^T = V^T.P^T
+template <typename T, int DH, bool FULL>
+__global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs a) {
+  constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);            // [64][LDK]
-  T* Vs = Ks + 64 * LDK;                         // fp32: [64][LDK] natural; bf16: [DH][LDT] transposed
-  T* Ps = Vs + (ACfg<T>::TR ? DH * LDT : 64 * LDK);  // [4][16][LDP]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  T* Vs = Ks + 64 * LDK;                         // [64][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
   const int64_t b = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
@@ -157,234 +243,209 @@ __global__ void __launch_bounds__(256) mha_fwd_kernel(AttnArgs a) {
   int64_t kv_end = a.Tk;
   if (a.mask_mode == NEURST_MASK_CAUSAL) kv_end = q0 + 64 < a.Tk ? q0 + 64 : a.Tk;
   else if (a.mask_mode == NEURST_MASK_KEYPAD && len > 0 && len < a.Tk) kv_end = len;
+  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
+  const float unit = SM<T>::unit(), c = a.qscale * unit;
 
   typename Mma<T>::Frag qf[DH / KS];
   load_frags_global<T, DH>(qf, qg, a.ldq, q0 + w * 16, a.Tq, dh, a.q_aligned, lane);
 
-  f32x4 oacc[DH / 16];
+  f32x4 oacc[DH / 16];   // O^T: lane = query (l & 15), rows = head columns 16 dt + g4 + r
 #pragma unroll
   for (int i = 0; i < DH / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[4], l_run[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
-  T* Pw = Ps + w * 16 * LDP;
-  const int64_t bh = b * a.H + h;
-  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
-  uint64_t rowb[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) rowb[r] = (uint64_t)((bh * a.Tq + q0 + w * 16 + (lane >> 4) * 4 + r) * a.Tk);
+  float m_run = -INFINITY, l_run = 0.f;
+  const int64_t bh = b * a.H + h, qi = q0 + w * 16 + (lane & 15);
+  const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
 
+  TileRegs<T, DH, FULL> kreg, vreg;
+  kreg.load(kg, a.ldk, 0, a.Tk, dh, a.k_aligned, tid);
+  vreg.load(vg, a.ldv, 0, a.Tk, dh, a.v_aligned, tid);
   for (int64_t kv0 = 0; kv0 < kv_end; kv0 += 64) {
     __syncthreads();
-    stage_natural<T, DH>(Ks, kg, a.ldk, kv0, a.Tk, dh, a.k_aligned, tid);
-    if constexpr (ACfg<T>::TR) stage_transposed<T, DH>(Vs, vg, a.ldv, kv0, a.Tk, dh, a.v_aligned, tid);
-    else stage_natural<T, DH>(Vs, vg, a.ldv, kv0, a.Tk, dh, a.v_aligned, tid);
+    kreg.store(Ks, tid);
+    vreg.store(Vs, tid);
     __syncthreads();
+    if (kv0 + 64 < kv_end) {   // next tile: in flight while this one is multiplied
+      kreg.load(kg, a.ldk, kv0 + 64, a.Tk, dh, a.k_aligned, tid);
+      vreg.load(vg, a.ldv, kv0 + 64, a.Tk, dh, a.v_aligned, tid);
+    }
     f32x4 s[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < DH / KS; ++ks)
-        s[nt] = Mma<T>::mma(qf[ks], Mma<T>::load(Ks + nt * 16 * LDK + ks * KS, LDK, lane), s[nt]);
+        s[nt] = Mma<T>::mma(Mma<T>::load(Ks + nt * 16 * LDK + ks * KS, LDK, lane), qf[ks], s[nt]);
+      SCHED_FENCE();
     }
-    float mloc[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim;   // wave-uniform: tile touches a bias or the tensor end
+    float mloc = -INFINITY;
     if (edge) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
-          float v = biased_score(s[nt][r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
-          s[nt][r] = v;
-          mloc[r] = fmaxf(mloc[r], v);
+          s[nt][r] = biased_score(s[nt][r], c, unit, qi, kv0 + nt * 16 + g4 + r, a.Tk, a.mask_mode, len);
+          mloc = fmaxf(mloc, s[nt][r]);
         }
     } else {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[nt][r] * a.qscale;
-          s[nt][r] = v;
-          mloc[r] = fmaxf(mloc[r], v);
-        }
+        for (int r = 0; r < 4; ++r) { s[nt][r] *= c; mloc = fmaxf(mloc, s[nt][r]); }
     }
-    float alpha[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float mn = fmaxf(m_run[r], group16_max(mloc[r]));
-      alpha[r] = (m_run[r] == -INFINITY) ? 0.f : fast_exp<T>(m_run[r] - mn);
-      m_run[r] = mn;
-      l_run[r] *= alpha[r];
-    }
-#pragma unroll
-    for (int i = 0; i < DH / 16; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[i][r] *= alpha[r];
-    const int kcol = (int)kv0 + (lane & 15);
+    const float mn = fmaxf(m_run, quad_groups_max(mloc));
+    const float alpha = (m_run == -INFINITY) ? 0.f : SM<T>::ex(m_run - mn);
+    m_run = mn;
+    float lsum = 0.f;
+    const uint32_t kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float p = (edge && s[nt][r] == -INFINITY) ? 0.f : fast_exp<T>(s[nt][r] - m_run[r]);
-        l_run[r] += p;
-        if (a.thr) p = attn_keep(a, rowb[r], kcol + nt * 16) ? p * a.keep_scale : 0.f;
-        Pw[((lane >> 4) * 4 + r) * LDP + nt * 16 + (lane & 15)] = from_f32<T>(p);
+        float p = (edge && s[nt][r] == -INFINITY) ? 0.f : SM<T>::ex(s[nt][r] - mn);
+        lsum += p;
+        if (a.thr) p = ((kmask >> (nt * 4 + r)) & 1u) ? p * a.keep_scale : 0.f;
+        s[nt][r] = p;
       }
-    wave_lds_sync();
+    l_run = l_run * alpha + lsum;
 #pragma unroll
-    for (int ks2 = 0; ks2 < 64 / KS; ++ks2) {
-      typename Mma<T>::Frag pf = Mma<T>::load(Pw + ks2 * KS, LDP, lane);
+    for (int i = 0; i < DH / 16; ++i) oacc[i] *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < DH / 16; ++dt)
-        oacc[dt] = Mma<T>::mma(pf, load_b_rowk<T>(Vs, LDK, Vs, LDT, ks2 * KS, dt * 16, lane), oacc[dt]);
-    }
-  }
-  T* og = reinterpret_cast<T*>(a.out) + b * a.bso + h * dh;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float l = group16_sum(l_run[r]);
-    const float inv = 1.f / l;
-    const int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r;
-    if (qi < a.Tq) {
+    for (int st = 0; st < RegP<T>::NSTEP; ++st) {
+      const typename Mma<T>::Frag pf = RegP<T>::bfrag(s, st);
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
-        int c = dt * 16 + (lane & 15);
-        if (c < dh) og[qi * a.ldo + c] = from_f32<T>(oacc[dt][r] * inv);
+        oacc[dt] = Mma<T>::mma(RegP<T>::afrag_tr(Vs, LDK, st, dt * 16, lane), pf, oacc[dt]);
+        if (dt & 1) SCHED_FENCE();
       }
-      if ((lane & 15) == 0) a.lse[bh * a.Tq + qi] = m_run[r] + logf(l);
     }
   }
-}
-
-// ================================================================== delta = rowsum(dO * O)
-template <typename T>
-__global__ void mha_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ delta, int64_t ldo, int64_t B,
-                                 int64_t H, int64_t Tq, int dh) {
-  const int lane = threadIdx.x & 63;
-  const int64_t total = B * H * Tq;
-  for (int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (int64_t)gridDim.x * 4) {
-    int64_t qi = i % Tq, bh = i / Tq;
-    int64_t h = bh % H, b = bh / H;
-    const int64_t off = (b * Tq + qi) * ldo + h * dh;
-    float s = 0.f;
-    for (int c = lane; c < dh; c += 64) s += to_f32<T>(o[off + c]) * to_f32<T>(d_o[off + c]);
-    s = wave_sum(s);
-    if (lane == 0) delta[i] = s;
+  const float l = quad_groups_sum(l_run);
+  const float inv = 1.f / l;
+  if (qi < a.Tq) {
+    T* orow = reinterpret_cast<T*>(a.out) + b * a.bso + h * dh + qi * a.ldo;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) store4<T>(orow, dt * 16 + g4, dh, oacc[dt] * inv, a.out_vec);
+    if (lane < 16) a.lse[bh * a.Tq + qi] = SM<T>::lse(m_run, l) ;
   }
 }
 
-// ================================================================== backward: dQ
-template <typename T, int DH>
-__global__ void __launch_bounds__(256) mha_bwd_dq_kernel(AttnArgs a) {
-  constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD, LDT = 64 + ACfg<T>::PAD, LDP = 64 + ACfg<T>::PAD;
+// ================================================================== backward: delta + dQ
+// lane l works for query (l & 15): S^T = K.Q^T, dP^T = V.dO^T, dQ^T = K^T.dS^T; also writes delta = rowsum(dO * O)
+template <typename T, int DH, bool FULL>
+__global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArgs a) {
+  constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);             // [64][LDK]
   T* Vs = Ks + 64 * LDK;                          // [64][LDK]
-  T* Kt = Vs + 64 * LDK;                          // bf16 only: [DH][LDT]
-  T* Ps = Kt + (ACfg<T>::TR ? DH * LDT : 0);      // [4][16][LDP]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
   const int64_t b = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
   const T* kg = reinterpret_cast<const T*>(a.k) + b * a.bsk + h * dh;
   const T* vg = reinterpret_cast<const T*>(a.v) + b * a.bsv + h * dh;
+  const T* og = reinterpret_cast<const T*>(a.o) + b * a.bso + h * dh;
   const T* dog = reinterpret_cast<const T*>(a.d_o) + b * a.bso + h * dh;
   const int len = a.mask_mode == NEURST_MASK_KEYPAD ? a.len_k[b] : 0;
   int64_t kv_end = a.Tk;
   if (a.mask_mode == NEURST_MASK_CAUSAL) kv_end = q0 + 64 < a.Tk ? q0 + 64 : a.Tk;
   else if (a.mask_mode == NEURST_MASK_KEYPAD && len > 0 && len < a.Tk) kv_end = len;
-  const int64_t bh = b * a.H + h;
+  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
+  const int64_t bh = b * a.H + h, qi = q0 + w * 16 + (lane & 15);
+  const bool q_tail = q0 + 64 > a.Tq;
+  const float unit = SM<T>::unit(), c = a.qscale * unit;
 
   typename Mma<T>::Frag qf[DH / KS], dof[DH / KS];
   load_frags_global<T, DH>(qf, qg, a.ldq, q0 + w * 16, a.Tq, dh, a.q_aligned, lane);
   load_frags_global<T, DH>(dof, dog, a.ldo, q0 + w * 16, a.Tq, dh, a.o_aligned, lane);
-  float lse_r[4], del_r[4];
+  float del;
+  {
+    typename Mma<T>::Frag of[DH / KS];
+    load_frags_global<T, DH>(of, og, a.ldo, q0 + w * 16, a.Tq, dh, a.o_aligned, lane);
+    float d = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r;
-    lse_r[r] = qi < a.Tq ? a.lse_in[bh * a.Tq + qi] : 0.f;
-    del_r[r] = qi < a.Tq ? a.delta[bh * a.Tq + qi] : 0.f;
+    for (int ks = 0; ks < DH / KS; ++ks) {
+      if constexpr (sizeof(T) == 4) d += of[ks] * dof[ks];
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += (float)of[ks][j] * (float)dof[ks][j];
+      }
+    }
+    del = quad_groups_sum(d);
+    if (lane < 16 && qi < a.Tq) a.delta[bh * a.Tq + qi] = del;
   }
+  const float lse_q = (qi < a.Tq ? a.lse_in[bh * a.Tq + qi] : 0.f) * unit;
+  const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
   f32x4 dqacc[DH / 16];
 #pragma unroll
   for (int i = 0; i < DH / 16; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  T* Pw = Ps + w * 16 * LDP;
-  const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
-  const bool q_tail = q0 + 64 > a.Tq;
-  uint64_t rowb[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) rowb[r] = (uint64_t)((bh * a.Tq + q0 + w * 16 + (lane >> 4) * 4 + r) * a.Tk);
 
+  TileRegs<T, DH, FULL> kreg, vreg;
+  kreg.load(kg, a.ldk, 0, a.Tk, dh, a.k_aligned, tid);
+  vreg.load(vg, a.ldv, 0, a.Tk, dh, a.v_aligned, tid);
   for (int64_t kv0 = 0; kv0 < kv_end; kv0 += 64) {
     __syncthreads();
-    stage_natural<T, DH>(Ks, kg, a.ldk, kv0, a.Tk, dh, a.k_aligned, tid);
-    stage_natural<T, DH>(Vs, vg, a.ldv, kv0, a.Tk, dh, a.v_aligned, tid);
-    if constexpr (ACfg<T>::TR) stage_transposed<T, DH>(Kt, kg, a.ldk, kv0, a.Tk, dh, a.k_aligned, tid);
+    kreg.store(Ks, tid);
+    vreg.store(Vs, tid);
     __syncthreads();
+    if (kv0 + 64 < kv_end) {
+      kreg.load(kg, a.ldk, kv0 + 64, a.Tk, dh, a.k_aligned, tid);
+      vreg.load(vg, a.ldv, kv0 + 64, a.Tk, dh, a.v_aligned, tid);
+    }
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q_tail;
-    const int kcol = (int)kv0 + (lane & 15);
+    const uint32_t kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+    f32x4 ds[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < DH / KS; ++ks) {
-        s = Mma<T>::mma(qf[ks], Mma<T>::load(Ks + nt * 16 * LDK + ks * KS, LDK, lane), s);
-        dp = Mma<T>::mma(dof[ks], Mma<T>::load(Vs + nt * 16 * LDK + ks * KS, LDK, lane), dp);
+        s = Mma<T>::mma(Mma<T>::load(Ks + nt * 16 * LDK + ks * KS, LDK, lane), qf[ks], s);
+        dp = Mma<T>::mma(Mma<T>::load(Vs + nt * 16 * LDK + ks * KS, LDK, lane), dof[ks], dp);
       }
+      SCHED_FENCE();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float p;
         if (edge) {
-          int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r, kj = kv0 + nt * 16 + (lane & 15);
-          float sc = biased_score(s[r], a.qscale, qi, kj, a.Tk, a.mask_mode, len);
-          p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : fast_exp<T>(sc - lse_r[r]);
+          const float sc = biased_score(s[r], c, unit, qi, kv0 + nt * 16 + g4 + r, a.Tk, a.mask_mode, len);
+          p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : SM<T>::ex(sc - lse_q);
         } else {
-          p = fast_exp<T>(s[r] * a.qscale - lse_r[r]);
+          p = SM<T>::ex(s[r] * c - lse_q);
         }
         float dpe = dp[r];
-        if (a.thr) dpe = attn_keep(a, rowb[r], kcol + nt * 16) ? dpe * a.keep_scale : 0.f;
-        Pw[((lane >> 4) * 4 + r) * LDP + nt * 16 + (lane & 15)] = from_f32<T>(p * (dpe - del_r[r]));
+        if (a.thr) dpe = ((kmask >> (nt * 4 + r)) & 1u) ? dpe * a.keep_scale : 0.f;
+        ds[nt][r] = p * (dpe - del);
       }
     }
-    wave_lds_sync();
 #pragma unroll
-    for (int ks2 = 0; ks2 < 64 / KS; ++ks2) {
-      typename Mma<T>::Frag pf = Mma<T>::load(Pw + ks2 * KS, LDP, lane);
-#pragma unroll
-      for (int dt = 0; dt < DH / 16; ++dt)
-        dqacc[dt] = Mma<T>::mma(pf, load_b_rowk<T>(Ks, LDK, Kt, LDT, ks2 * KS, dt * 16, lane), dqacc[dt]);
-    }
-  }
-  T* dqg = reinterpret_cast<T*>(a.dq) + b * a.Tq * a.lddq + h * dh;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t qi = q0 + w * 16 + (lane >> 4) * 4 + r;
-    if (qi < a.Tq) {
+    for (int st = 0; st < RegP<T>::NSTEP; ++st) {
+      const typename Mma<T>::Frag dsf = RegP<T>::bfrag(ds, st);
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
-        int c = dt * 16 + (lane & 15);
-        if (c < dh) dqg[qi * a.lddq + c] = from_f32<T>(dqacc[dt][r] * a.qscale);
+        dqacc[dt] = Mma<T>::mma(RegP<T>::afrag_tr(Ks, LDK, st, dt * 16, lane), dsf, dqacc[dt]);
+        if (dt & 1) SCHED_FENCE();
       }
     }
+  }
+  if (qi < a.Tq) {
+    T* dqrow = reinterpret_cast<T*>(a.dq) + b * a.Tq * a.lddq + h * dh + qi * a.lddq;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dqrow, dt * 16 + g4, dh, dqacc[dt] * a.qscale, a.dq_vec);
   }
 }
 
 // ================================================================== backward: dK, dV
-template <typename T, int DH>
-__global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
-  constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD, LDT = 64 + ACfg<T>::PAD, LDP = 64 + ACfg<T>::PAD;
+// workgroup = 64 keys (16 per wave); lane l works for key (l & 15): S = Q.K^T, dP = dO.V^T, dV^T = dO^T.P, dK^T = Q^T.dS
+template <typename T, int DH, bool FULL>
+__global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Qs = reinterpret_cast<T*>(smem);                 // [64][LDK]
   T* dOs = Qs + 64 * LDK;                             // [64][LDK]
-  T* Qt = dOs + 64 * LDK;                             // bf16 only [DH][LDT]
-  T* dOt = Qt + (ACfg<T>::TR ? DH * LDT : 0);         // bf16 only [DH][LDT]
-  T* Ps = dOt + (ACfg<T>::TR ? DH * LDT : 0);         // [4][16][LDP]  dropped P^T
-  T* dSs = Ps + 4 * 16 * LDP;                         // [4][16][LDP]  dS^T
-  float* lse_s = reinterpret_cast<float*>(dSs + 4 * 16 * LDP);  // [64]
+  float* lse_s = reinterpret_cast<float*>(dOs + 64 * LDK);  // [64]
   float* del_s = lse_s + 64;                          // [64]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
   const int64_t b = blockIdx.z, h = blockIdx.y, kv0 = (int64_t)blockIdx.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
@@ -392,8 +453,9 @@ __global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
   const T* vg = reinterpret_cast<const T*>(a.v) + b * a.bsv + h * dh;
   const T* dog = reinterpret_cast<const T*>(a.d_o) + b * a.bso + h * dh;
   const int len = a.mask_mode == NEURST_MASK_KEYPAD ? a.len_k[b] : 0;
-  const int64_t bh = b * a.H + h;
+  const int64_t bh = b * a.H + h, kj = kv0 + w * 16 + (lane & 15);
   const bool dead = a.mask_mode == NEURST_MASK_KEYPAD && len > 0 && kv0 >= len;  // padded keys get exactly zero weight
+  const float unit = SM<T>::unit(), c = a.qscale * unit;
 
   typename Mma<T>::Frag kf[DH / KS], vf[DH / KS];
   load_frags_global<T, DH>(kf, kg, a.ldk, kv0 + w * 16, a.Tk, dh, a.k_aligned, lane);
@@ -401,103 +463,109 @@ __global__ void __launch_bounds__(256) mha_bwd_dkv_kernel(AttnArgs a) {
   f32x4 dkacc[DH / 16], dvacc[DH / 16];
 #pragma unroll
   for (int i = 0; i < DH / 16; ++i) { dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  T* Pw = Ps + w * 16 * LDP;
-  T* dSw = dSs + w * 16 * LDP;
   int64_t q_begin = 0;
   if (a.mask_mode == NEURST_MASK_CAUSAL) q_begin = kv0;  // queries before the first key of this tile are fully masked
   if (dead) q_begin = a.Tq;
   const int64_t kv_lim = a.mask_mode == NEURST_MASK_KEYPAD ? (len < a.Tk ? len : a.Tk) : a.Tk;
 
+  TileRegs<T, DH, FULL> qreg, doreg;
+  float lse_reg = 0.f, del_reg = 0.f;   // threads 0..63: statistics of query q0 + tid of the staged tile
+  auto load_stats = [&](int64_t q0n) {
+    const int64_t qi = q0n + tid;
+    if (tid < 64 && qi < a.Tq) { lse_reg = a.lse_in[bh * a.Tq + qi] * unit; del_reg = a.delta[bh * a.Tq + qi]; }
+    else { lse_reg = 0.f; del_reg = 0.f; }
+  };
+  if (q_begin < a.Tq) {
+    qreg.load(qg, a.ldq, q_begin, a.Tq, dh, a.q_aligned, tid);
+    doreg.load(dog, a.ldo, q_begin, a.Tq, dh, a.o_aligned, tid);
+    load_stats(q_begin);
+  }
   for (int64_t q0 = q_begin; q0 < a.Tq; q0 += 64) {
-    __syncthreads();
-    stage_natural<T, DH>(Qs, qg, a.ldq, q0, a.Tq, dh, a.q_aligned, tid);
-    stage_natural<T, DH>(dOs, dog, a.ldo, q0, a.Tq, dh, a.o_aligned, tid);
-    if constexpr (ACfg<T>::TR) {
-      stage_transposed<T, DH>(Qt, qg, a.ldq, q0, a.Tq, dh, a.q_aligned, tid);
-      stage_transposed<T, DH>(dOt, dog, a.ldo, q0, a.Tq, dh, a.o_aligned, tid);
+#if !DKV_PREFETCH
+    if (q0 > q_begin) {
+      qreg.load(qg, a.ldq, q0, a.Tq, dh, a.q_aligned, tid);
+      doreg.load(dog, a.ldo, q0, a.Tq, dh, a.o_aligned, tid);
+      load_stats(q0);
     }
-    if (tid < 64) {
-      int64_t qi = q0 + tid;
-      lse_s[tid] = qi < a.Tq ? a.lse_in[bh * a.Tq + qi] : 0.f;
-      del_s[tid] = qi < a.Tq ? a.delta[bh * a.Tq + qi] : 0.f;
-    }
+#endif
     __syncthreads();
+    qreg.store(Qs, tid);
+    doreg.store(dOs, tid);
+    if (tid < 64) { lse_s[tid] = lse_reg; del_s[tid] = del_reg; }
+    __syncthreads();
+#if DKV_PREFETCH
+    if (q0 + 64 < a.Tq) {
+      qreg.load(qg, a.ldq, q0 + 64, a.Tq, dh, a.q_aligned, tid);
+      doreg.load(dog, a.ldo, q0 + 64, a.Tq, dh, a.o_aligned, tid);
+      load_stats(q0 + 64);
+    }
+#endif
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q0 + 64 > a.Tq;
+    const uint32_t kmask = keep_bits16(a, (uint64_t)((bh * a.Tq + q0) * a.Tk) + (uint64_t)kj, g4 * (int)a.Tk, 16 * (int)a.Tk, (int)a.Tk);
+    // two halves of 32 queries: the probabilities of a half are consumed by the second products right away
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      f32x4 pacc[2], dsacc[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+      for (int n2 = 0; n2 < 2; ++n2) {
+        const int nt = half * 2 + n2;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < DH / KS; ++ks) {
-        st = Mma<T>::mma(kf[ks], Mma<T>::load(Qs + nt * 16 * LDK + ks * KS, LDK, lane), st);
-        dpt = Mma<T>::mma(vf[ks], Mma<T>::load(dOs + nt * 16 * LDK + ks * KS, LDK, lane), dpt);
-      }
-      const int qloc = nt * 16 + (lane & 15);
-      const int64_t qi = q0 + qloc;
-      const float lse_q = lse_s[qloc], del_q = del_s[qloc];
-      const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kcol = (int)kv0 + w * 16 + (lane >> 4) * 4 + r;
-        float p;
-        if (edge) {
-          float sc = biased_score(st[r], a.qscale, qi, (int64_t)kcol, a.Tk, a.mask_mode, len);
-          p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : fast_exp<T>(sc - lse_q);
-        } else {
-          p = fast_exp<T>(st[r] * a.qscale - lse_q);
+        for (int ks = 0; ks < DH / KS; ++ks) {
+          s = Mma<T>::mma(Mma<T>::load(Qs + nt * 16 * LDK + ks * KS, LDK, lane), kf[ks], s);
+          dp = Mma<T>::mma(Mma<T>::load(dOs + nt * 16 * LDK + ks * KS, LDK, lane), vf[ks], dp);
         }
-        float pd = p, dpe = dpt[r];
-        if (a.thr) {
-          bool keep = attn_keep(a, rowb, kcol);
-          pd = keep ? p * a.keep_scale : 0.f;
-          dpe = keep ? dpe * a.keep_scale : 0.f;
+        SCHED_FENCE();
+        const int qloc = nt * 16 + g4;
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + qloc), del4 = *reinterpret_cast<const f32x4*>(del_s + qloc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t qi = q0 + qloc + r;
+          float p;
+          if (edge) {
+            const float sc = biased_score(s[r], c, unit, qi, kj, a.Tk, a.mask_mode, len);
+            p = (sc == -INFINITY || qi >= a.Tq) ? 0.f : SM<T>::ex(sc - lse4[r]);
+          } else {
+            p = SM<T>::ex(s[r] * c - lse4[r]);
+          }
+          float pd = p, dpe = dp[r];
+          if (a.thr) {
+            const bool keep = (kmask >> (nt * 4 + r)) & 1u;
+            pd = keep ? p * a.keep_scale : 0.f;
+            dpe = keep ? dpe * a.keep_scale : 0.f;
+          }
+          pacc[n2][r] = pd;
+          dsacc[n2][r] = p * (dpe - del4[r]);
         }
-        Pw[((lane >> 4) * 4 + r) * LDP + qloc] = from_f32<T>(pd);
-        dSw[((lane >> 4) * 4 + r) * LDP + qloc] = from_f32<T>(p * (dpe - del_q));
       }
-    }
-    wave_lds_sync();
 #pragma unroll
-    for (int ks2 = 0; ks2 < 64 / KS; ++ks2) {
-      typename Mma<T>::Frag pf = Mma<T>::load(Pw + ks2 * KS, LDP, lane);
-      typename Mma<T>::Frag dsf = Mma<T>::load(dSw + ks2 * KS, LDP, lane);
+      for (int ls = 0; ls < RegP<T>::NSTEP / 2; ++ls) {
+        const int st = half * (RegP<T>::NSTEP / 2) + ls;
+        const typename Mma<T>::Frag pf = RegP<T>::bfrag_half(pacc, ls), dsf = RegP<T>::bfrag_half(dsacc, ls);
 #pragma unroll
-      for (int dt = 0; dt < DH / 16; ++dt) {
-        dvacc[dt] = Mma<T>::mma(pf, load_b_rowk<T>(dOs, LDK, dOt, LDT, ks2 * KS, dt * 16, lane), dvacc[dt]);
-        dkacc[dt] = Mma<T>::mma(dsf, load_b_rowk<T>(Qs, LDK, Qt, LDT, ks2 * KS, dt * 16, lane), dkacc[dt]);
+        for (int dt = 0; dt < DH / 16; ++dt) {
+          dvacc[dt] = Mma<T>::mma(RegP<T>::afrag_tr(dOs, LDK, st, dt * 16, lane), pf, dvacc[dt]);
+          dkacc[dt] = Mma<T>::mma(RegP<T>::afrag_tr(Qs, LDK, st, dt * 16, lane), dsf, dkacc[dt]);
+          SCHED_FENCE();
+        }
       }
     }
   }
-  T* dkg = reinterpret_cast<T*>(a.dk) + b * a.Tk * a.lddk + h * dh;
-  T* dvg = reinterpret_cast<T*>(a.dv) + b * a.Tk * a.lddv + h * dh;
+  if (kj < a.Tk) {
+    T* dkrow = reinterpret_cast<T*>(a.dk) + b * a.Tk * a.lddk + h * dh + kj * a.lddk;
+    T* dvrow = reinterpret_cast<T*>(a.dv) + b * a.Tk * a.lddv + h * dh + kj * a.lddv;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t kj = kv0 + w * 16 + (lane >> 4) * 4 + r;
-    if (kj < a.Tk) {
-#pragma unroll
-      for (int dt = 0; dt < DH / 16; ++dt) {
-        int c = dt * 16 + (lane & 15);
-        if (c < dh) {
-          dkg[kj * a.lddk + c] = from_f32<T>(dkacc[dt][r] * a.qscale);
-          dvg[kj * a.lddv + c] = from_f32<T>(dvacc[dt][r]);
-        }
-      }
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      store4<T>(dkrow, dt * 16 + g4, dh, dkacc[dt] * a.qscale, a.dk_vec);
+      store4<T>(dvrow, dt * 16 + g4, dh, dvacc[dt], a.dv_vec);
     }
   }
 }
 
 // ================================================================== host side
-template <typename T, int DH> static size_t fwd_smem() {
-  constexpr int LDK = DH + ACfg<T>::PAD, LDT = 64 + ACfg<T>::PAD, LDP = 64 + ACfg<T>::PAD;
-  return sizeof(T) * (64 * LDK + (ACfg<T>::TR ? DH * LDT : 64 * LDK) + 4 * 16 * LDP);
-}
-template <typename T, int DH> static size_t dq_smem() {
-  constexpr int LDK = DH + ACfg<T>::PAD, LDT = 64 + ACfg<T>::PAD, LDP = 64 + ACfg<T>::PAD;
-  return sizeof(T) * (2 * 64 * LDK + (ACfg<T>::TR ? DH * LDT : 0) + 4 * 16 * LDP);
-}
-template <typename T, int DH> static size_t dkv_smem() {
-  constexpr int LDK = DH + ACfg<T>::PAD, LDT = 64 + ACfg<T>::PAD, LDP = 64 + ACfg<T>::PAD;
-  return sizeof(T) * (2 * 64 * LDK + (ACfg<T>::TR ? 2 * DH * LDT : 0) + 8 * 16 * LDP) + 128 * sizeof(float);
-}
+template <typename T, int DH> static size_t fwd_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
+template <typename T, int DH> static size_t dq_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
+template <typename T, int DH> static size_t dkv_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD) + 128 * sizeof(float); }
 
 template <typename K>
 static int launch_attn(K kernel, dim3 grid, size_t smem, const AttnArgs& a, hipStream_t s, const char* name) {
@@ -530,17 +598,23 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
   size_t es = dtype_size(dtype);
   auto al = [&](const void* p, int64_t ld) { return (int)((((uintptr_t)p & 15) == 0) && ((ld * es) % 16 == 0) && ((dh * es) % 16 == 0)); };
   a.q_aligned = al(a.q, a.ldq); a.k_aligned = al(a.k, a.ldk); a.v_aligned = al(a.v, a.ldv);
-  a.o_aligned = a.d_o ? al(a.d_o, a.ldo) : 1;
+  a.o_aligned = a.d_o ? (al(a.d_o, a.ldo) && al(a.o, a.ldo)) : 1;
+  auto v4 = [&](const void* p, int64_t ld, int64_t bs) { return (int)(p && (((uintptr_t)p % (4 * es)) == 0) && (ld % 4 == 0) && (bs % 4 == 0) && (dh % 4 == 0)); };
+  a.out_vec = v4(a.out, a.ldo, a.bso); a.dq_vec = v4(a.dq, a.lddq, 0); a.dk_vec = v4(a.dk, a.lddk, 0); a.dv_vec = v4(a.dv, a.lddv, 0);
   return NEURST_OK;
 }
 
+#define DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, D)                                                            \
+  rc = (full && dh == D) ? launch_attn(KERNEL<T, D, true>, GRID, SMEMFN<T, D>(), a, s, NAME)                      \
+                         : launch_attn(KERNEL<T, D, false>, GRID, SMEMFN<T, D>(), a, s, NAME)
 #define DISPATCH_DH(T, KERNEL, SMEMFN, GRID, NAME)                                                       \
   do {                                                                                                   \
-    if (dh <= 32) rc = launch_attn(KERNEL<T, 32>, GRID, SMEMFN<T, 32>(), a, s, NAME);                    \
-    else if (dh <= 64) rc = launch_attn(KERNEL<T, 64>, GRID, SMEMFN<T, 64>(), a, s, NAME);               \
-    else if (dh <= 96) rc = launch_attn(KERNEL<T, 96>, GRID, SMEMFN<T, 96>(), a, s, NAME);               \
-    else if (dh <= 128) rc = launch_attn(KERNEL<T, 128>, GRID, SMEMFN<T, 128>(), a, s, NAME);            \
-    else rc = launch_attn(KERNEL<T, 192>, GRID, SMEMFN<T, 192>(), a, s, NAME);                           \
+    const bool full = sizeof(T) == 2 && a.q_aligned && a.k_aligned && a.v_aligned && a.o_aligned;        \
+    if (dh <= 32) DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 32);                                       \
+    else if (dh <= 64) DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 64);                                  \
+    else if (dh <= 96) DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 96);                                  \
+    else if (dh <= 128) DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 128);                                \
+    else DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 192);                                               \
   } while (0)
 
 extern "C" int neurst_mha_fwd_strided(const void* q, const void* k, const void* v, void* o, float* lse, int64_t ldq, int64_t ldk,
@@ -586,11 +660,6 @@ extern "C" int neurst_mha_bwd(const void* q, const void* k, const void* v, const
   NEURST_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh && lddq >= H * dh && lddk >= H * dh && lddv >= H * dh,
                    "mha_bwd: row stride smaller than H*dh");
   hipStream_t s = as_stream(stream);
-  int64_t nrows = B * H * Tq;
-  int dgrid = (int)(cdiv64(nrows, 4) > 8192 ? 8192 : cdiv64(nrows, 4));
-  if (dtype == NEURST_BF16) mha_delta_kernel<bf16_t><<<dgrid, 256, 0, s>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, ldo, B, H, Tq, (int)dh);
-  else mha_delta_kernel<float><<<dgrid, 256, 0, s>>>((const float*)o, (const float*)d_o, delta, ldo, B, H, Tq, (int)dh);
-  NEURST_CHECK_LAUNCH("mha_delta");
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)H, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)H, (unsigned)B);
   if (dtype == NEURST_BF16) DISPATCH_DH(bf16_t, mha_bwd_dq_kernel, dq_smem, gq, "mha_bwd_dq");
