@@ -173,19 +173,21 @@ __device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __re
 constexpr int EPI_LD = 68;                                   // fp32 row stride of the per-wave epilogue tile
 constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;               // 4 waves x 32 rows x 68 floats
 
-template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST, int SUMOP = 0>
+template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST, int SUMOP = 0, int NS = 2>
 __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   // TB_KCONTIG: B stored [N][K] (trans_b = 1); otherwise B stored [K][N].  TA: A stored [K][M].
   // FAST (bf16, aligned operands): full K-tiles go global -> LDS directly (no VGPR staging).
+  // NS = LDS stages.  2: three workgroups per CU hide each other's load latency (large grids).  4: for grids of at most
+  // one workgroup per CU - three K-tiles (96 KB) stay in flight per CU across raw barriers with counted vmcnt waits.
   constexpr int BK = GemmCfg<T>::BK;
   typedef Stager<T, TA> SA;
   typedef Stager<T, !TB_KCONTIG> SB;
-  constexpr int STAGE_BYTES = 2 * (SA::TILE + SB::TILE) * (int)sizeof(T);
+  constexpr int STAGE_BYTES = NS * (SA::TILE + SB::TILE) * (int)sizeof(T);
   constexpr int SMEM = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];   // ONE LDS object (staging ring, then epilogue tiles)
   T* const lds = reinterpret_cast<T*>(smem);
   auto As = [&](int b) -> T* { return lds + b * SA::TILE; };
-  auto Bs = [&](int b) -> T* { return lds + 2 * SA::TILE + b * SB::TILE; };
+  auto Bs = [&](int b) -> T* { return lds + NS * SA::TILE + b * SB::TILE; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles
@@ -231,19 +233,48 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   int cur = 0;
   if constexpr (FAST) {
     const int nfull = (int)((kend - kbeg) / BK);
-    if (nfull > 0) {
-      issue_glds<T, TA>(A, g.lda, m0, kbeg, g.M, As(0), tid);
-      issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kbeg, g.N, Bs(0), tid);
-    }
-    for (int it = 0; it < nfull; ++it) {
-      __syncthreads();   // tile `it` has landed (vmcnt(0) precedes the barrier) and buf[cur^1] is no longer read
-      if (it + 1 < nfull) {
-        const int64_t kn = kbeg + (int64_t)(it + 1) * BK;
-        issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
-        issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
+    if constexpr (NS == 2) {
+      if (nfull > 0) {
+        issue_glds<T, TA>(A, g.lda, m0, kbeg, g.M, As(0), tid);
+        issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kbeg, g.N, Bs(0), tid);
       }
-      mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(kbeg + (int64_t)it * BK), wm, wn, lane);
-      cur ^= 1;
+      for (int it = 0; it < nfull; ++it) {
+        __syncthreads();   // tile `it` has landed (vmcnt(0) precedes the barrier) and buf[cur^1] is no longer read
+        if (it + 1 < nfull) {
+          const int64_t kn = kbeg + (int64_t)(it + 1) * BK;
+          issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
+          issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
+        }
+        mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(kbeg + (int64_t)it * BK), wm, wn, lane);
+        cur ^= 1;
+      }
+    } else {
+      // every thread issues LPT direct-to-LDS loads per K-tile; vmcnt counts them in order, so "at most LPT * n
+      // outstanding" means everything but the newest n tiles has landed
+      constexpr int LPT = SA::NCH + SB::NCH;
+      static_assert(LPT * (NS - 2) <= 63, "vmcnt field");
+      const int npro = nfull < NS - 1 ? nfull : NS - 1;
+      for (int t = 0; t < npro; ++t) {
+        issue_glds<T, TA>(A, g.lda, m0, kbeg + (int64_t)t * BK, g.M, As(t), tid);
+        issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kbeg + (int64_t)t * BK, g.N, Bs(t), tid);
+      }
+      for (int it = 0; it < nfull; ++it) {
+        const int issued = it + NS - 1 < nfull ? it + NS - 1 : nfull;
+        const int inflight = issued - it - 1;          // tiles newer than `it` already issued: 0 .. NS-2
+        if (inflight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * 2) : "memory");
+        else if (inflight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's share of tile `it` is in LDS; buffer (it-1)%NS is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + NS - 1 < nfull) {
+          const int nb = (cur + NS - 1) % NS;
+          const int64_t kn = kbeg + (int64_t)(it + NS - 1) * BK;
+          issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(nb), tid);
+          issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(nb), tid);
+        }
+        mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(kbeg + (int64_t)it * BK), wm, wn, lane);
+        cur = (cur + 1) % NS;
+      }
     }
     const int64_t ktail = kbeg + (int64_t)nfull * BK;
     if (ktail < kend) {   // partial K-tile: register staging with zero fill
@@ -401,14 +432,24 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   }
 }
 
+// grids of at most one workgroup per CU cannot hide load latency behind other workgroups: deep pipeline instead
+static inline bool small_grid(const GemmArgs& g) { return (int64_t)g.tiles_m * g.tiles_n * g.split_k <= 256 && g.K >= 4 * 64; }
+
+template <typename T, typename TC, bool FAST, int NS>
+static int launch_gemm_ns(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
+  dim3 grid(g.tiles_m * g.tiles_n, 1, g.split_k);
+  if (!trans_a && trans_b) gemm_kernel<T, TC, false, true, FAST, 0, NS><<<grid, NT, 0, s>>>(g);
+  else if (!trans_a && !trans_b) gemm_kernel<T, TC, false, false, FAST, 0, NS><<<grid, NT, 0, s>>>(g);
+  else if (trans_a && !trans_b) gemm_kernel<T, TC, true, false, FAST, 0, NS><<<grid, NT, 0, s>>>(g);
+  else gemm_kernel<T, TC, true, true, FAST, 0, NS><<<grid, NT, 0, s>>>(g);
+  return 0;
+}
 template <typename T, typename TC, bool FAST>
 static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
-  dim3 grid(g.tiles_m * g.tiles_n, 1, g.split_k);
-  if (!trans_a && trans_b) gemm_kernel<T, TC, false, true, FAST><<<grid, NT, 0, s>>>(g);
-  else if (!trans_a && !trans_b) gemm_kernel<T, TC, false, false, FAST><<<grid, NT, 0, s>>>(g);
-  else if (trans_a && !trans_b) gemm_kernel<T, TC, true, false, FAST><<<grid, NT, 0, s>>>(g);
-  else gemm_kernel<T, TC, true, true, FAST><<<grid, NT, 0, s>>>(g);
-  return 0;
+  if constexpr (FAST) {
+    if (small_grid(g)) return launch_gemm_ns<T, TC, true, 4>(g, trans_a, trans_b, s);
+  }
+  return launch_gemm_ns<T, TC, FAST, 2>(g, trans_a, trans_b, s);
 }
 
 static int fill_gemm_args(GemmArgs& g, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
@@ -434,6 +475,13 @@ static int fill_gemm_args(GemmArgs& g, const void* A, const void* B, void* C, in
 template <typename T, bool FAST>
 static void launch_wgrad(const GemmArgs& g, int which, hipStream_t s) {
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.split_k);
+  if constexpr (FAST) {
+    if (small_grid(g)) {
+      if (which == 1) gemm_kernel<T, float, true, false, true, 1, 4><<<grid, NT, 0, s>>>(g);
+      else gemm_kernel<T, float, true, false, true, 2, 4><<<grid, NT, 0, s>>>(g);
+      return;
+    }
+  }
   if (which == 1) gemm_kernel<T, float, true, false, FAST, 1><<<grid, NT, 0, s>>>(g);
   else gemm_kernel<T, float, true, false, FAST, 2><<<grid, NT, 0, s>>>(g);
 }

@@ -63,6 +63,22 @@ def test_gemm_variants(dtype, tol, ta, tb, M, N, K):
     assert relerr(host(C2), np.maximum(ref, 0) + 0.5) < tol
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize('M,N,K', [(1280, 768, 768), (200, 136, 10000), (128, 128, 256), (130, 72, 8 * 83)])
+def test_gemm_deep_pipeline_small_grids(ta, tb, M, N, K):
+    """aligned bf16 problems of at most 256 tiles take the 4-stage direct-to-LDS pipeline (counted vmcnt waits)"""
+    rng = np.random.default_rng(M + K)
+    A = bf16_round(rng.standard_normal((K, M) if ta else (M, K)))
+    B = bf16_round(rng.standard_normal((N, K) if tb else (K, N)))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64) + bias
+    C = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    for _ in range(3):      # repeated launches: a wait placed one tile early shows up as a rare wrong tile
+        C.zero_()
+        ops.gemm(dev(A, torch.bfloat16), dev(B, torch.bfloat16), C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias))
+        assert relerr(host(C), ref) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_gemm_splitk_and_relu_gate(dtype):
     rng = np.random.default_rng(5)
