@@ -124,16 +124,24 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--ragged', action='store_true')
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='debug: every rank uses cuda:0 and the gloo backend (exercises the N>1 code path on a 1-GPU box; not a measurement)')
     a = ap.parse_args()
+    if os.environ.get('NEURST_BENCH_WATCHDOG'):      # debug aid: dump every thread's stack if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['NEURST_BENCH_WATCHDOG']), exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if a.rehearse_one_gpu else local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if a.rehearse_one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
 
     from neurst_amd import ops

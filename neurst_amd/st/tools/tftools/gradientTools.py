@@ -6,7 +6,11 @@ stream as soon as backward has enqueued every gradient kernel of the bucket, ove
 rest of backward; the 1/world_size of the mean is folded into the Adam kernel.
 """
 import torch
+import os
+
 import torch.distributed as dist
+
+_DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
 
 
 class GradBucketer:
@@ -55,6 +59,8 @@ class GradBucketer:
         if self.launched[b]:
             return
         self.launched[b] = True
+        if _DEBUG:
+            print('[bucketer r%d] launch bucket %d of %d (%d handles so far)' % (dist.get_rank(), b, len(self.bounds), len(self.handles)), flush=True)
         s, e = self.bounds[b]
         view = self.store.grads[s:e]
         if self.comm_stream is not None:
@@ -72,8 +78,10 @@ class GradBucketer:
             return 1.0
         for b in range(len(self.bounds)):
             self._launch(b)
-        for h in self.handles:
+        for i, h in enumerate(self.handles):
             h.wait()
+            if _DEBUG:
+                print('[bucketer r%d] handle %d done' % (dist.get_rank(), i), flush=True)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         scale = 1.0 / self.world

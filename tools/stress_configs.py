@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""SURVEY.md 8(d) configs 2 (ragged), 3 (COSTT) and 5 (long utterances) plus greedy inference at full width on one
+MI355X: each case runs a few train steps, checks that the losses are finite and prints ms/step and frames/s.
+Usage: python tools/stress_configs.py [case ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neurst_amd.st.layers.arguments import build_args  # noqa: E402
+from neurst_amd.st.models.TransformerTPE import GlobalStep  # noqa: E402
+from neurst_amd.synthetic import make_batch  # noqa: E402
+
+CASES = {
+    # name: (config, B, Traw, L, ragged)
+    'lut_ragged': ('lut.yaml', 32, 1500, 40, True),
+    'costt': ('costt.yaml', 32, 1500, 80, False),
+    'costt_ragged': ('costt.yaml', 32, 1500, 80, True),
+    'lut_T1000': ('lut.yaml', 32, 3000, 40, False),
+    'lut_T2000': ('lut.yaml', 16, 6000, 40, True),
+}
+
+
+def run(name, steps=4):
+    cfg, B, Traw, L, ragged = CASES[name]
+    args = build_args(os.path.join(ROOT, 'configs', cfg), dim_output=10000, compute_dtype='bf16')
+    is_lut = args.model.loss_type == 'ctc_kd_ce'
+    model = args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
+    host = make_batch(B=B, Traw=Traw, V=10000, L=L, U=40, Lb=40, bert_dim=768 if is_lut else None, seed=5, ragged=ragged)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    model.train_step_async(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out4 = model.train_step_async(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    vals = out4.cpu().numpy()
+    T = -(-Traw // 3)
+    ok = bool(np.isfinite(vals).all())
+    print('%-14s B=%d Traw=%d (T=%d) L=%d ragged=%d: %7.2f ms/step %9.0f enc frames/s  loss=%s finite=%s peak_mem=%.1f GB'
+          % (name, B, Traw, T, L, ragged, dt * 1e3, B * T / dt, np.array2string(vals, precision=3), ok, torch.cuda.max_memory_allocated() / 2**30), flush=True)
+    assert ok, name
+    del model
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+
+
+def infer_case():
+    args = build_args(os.path.join(ROOT, 'configs', 'lut.yaml'), dim_output=10000, compute_dtype='bf16')
+    args.max_len = 40
+    model = args.Model(GlobalStep(0), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=False, args=args)
+    host = make_batch(B=8, Traw=1000, V=10000, L=40, U=40, Lb=40, bert_dim=None, seed=6, ragged=True)
+    t0 = time.perf_counter()
+    preds, preds_am = model.infer(host['feature'], host['len_fea'])
+    torch.cuda.synchronize()
+    print('greedy infer   B=8 Traw=1000: %.1f ms, preds %s, preds_am %s' % ((time.perf_counter() - t0) * 1e3, preds.shape, preds_am.shape), flush=True)
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(CASES) + ['infer']
+    for n in names:
+        if n == 'infer':
+            infer_case()
+        else:
+            run(n)
