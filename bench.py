@@ -38,6 +38,15 @@ def lut_step_flops(B, T, L, Lb, V, d=768, din=480, nenc=4, nenc2=4, ndec=4):
     return fwd, 3 * fwd
 
 
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md 'HBM'); None if not collected."""
+    path = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get('bytes_per_launch', {}).get(kernel_label)
+
+
 class KernelTimer:
     """HIP-event timing of individual launches on the stream they are issued on (the torch current stream)."""
 
@@ -52,9 +61,7 @@ class KernelTimer:
         def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw):
             if not timer.enabled:
                 return orig(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw)
-            name = 'gemm_kernel<%s,%s,%s>' % ('bf16' if A.dtype == torch.bfloat16 else 'f32',
-                                              'bf16' if C.dtype == torch.bfloat16 else 'f32',
-                                              {(False, True): 'NT', (False, False): 'NN', (True, False): 'TN'}[(bool(trans_a), bool(trans_b))])
+            name = ops.gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, kw.get('split_k', 1))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw)
@@ -71,8 +78,7 @@ class KernelTimer:
             e0.record()
             r = orig_w(A, B, C, opsum, which, M, N, K, lda, ldb, ldc, **kw)
             e1.record()
-            timer.records.setdefault('gemm_kernel<%s,f32,TN,+bias-grad>' % ('bf16' if A.dtype == torch.bfloat16 else 'f32'), []).append(
-                (e0, e1, 2.0 * M * N * K))
+            timer.records.setdefault(ops.gemm_kernel_label(A, C, M, N, K, True, False, kw.get('split_k', 1), True), []).append((e0, e1, 2.0 * M * N * K))
             return r
         ops.gemm_wgrad_bias = gemm_wgrad_bias
 
@@ -88,7 +94,7 @@ class KernelTimer:
 
 def cpu_baseline(threads):
     """The numpy fp32 oracle (a PORT of the reference graph - TF 1.15 cannot run here) on a bounded sample
-    of the same workload: LUT widths, B=8 x 1000 raw frames (T=334, BASELINE config 1), L=U=Lb=40, V=10000, mean of steps 2..4 of four fwd+bwd+Adam steps."""
+    of the same workload: LUT widths, B=8 x 1000 raw frames (T=334, BASELINE config 1), L=U=Lb=40, V=10000, mean of steps 2..7 of seven fwd+bwd+Adam steps."""
     import yaml
     from oracle.model import OracleTPE, TPEConfig, init_params, train_step
     from oracle import ops as oops
@@ -101,7 +107,7 @@ def cpu_baseline(threads):
     M = {k: np.zeros_like(v) for k, v in P.items()}
     V = {k: np.zeros_like(v) for k, v in P.items()}
     model = OracleTPE(cfg, is_train=True, dropout=False)
-    nstep = 3
+    nstep = 6
     train_step(model, P, M, V, batch, 1, 50000, 4e-4, 50000)      # untimed: page in BLAS, allocate
     t0 = time.time()
     for i in range(nstep):
@@ -109,7 +115,7 @@ def cpu_baseline(threads):
     dt = (time.time() - t0) / nstep
     T = batch['feature'].shape[1]
     return {'value': B * T / dt, 'unit': 'encoder frames/s', 'cores': threads, 'kind': 'port',
-            'sample': 'numpy fp32 oracle (BLAS threads = cores), LUT train step at BASELINE config 1: B=%d x %d raw frames (T=%d), L=U=Lb=%d, V=10000, dropout 0; %.2f s/step over 3 timed steps' % (B, Traw, T, Ln, dt)}
+            'sample': 'numpy fp32 oracle (BLAS threads = cores), LUT train step at BASELINE config 1: B=%d x %d raw frames (T=%d), L=U=Lb=%d, V=10000, dropout 0; %.2f s/step over %d timed steps' % (B, Traw, T, Ln, dt, nstep)}
 
 
 def main():
@@ -209,6 +215,7 @@ def main():
                 'step_algorithmic_tflop': tot / 1e12, 'step_achieved': tot / step_s / 1e12, 'step_frac': tot / step_s / 1e12 / peak}
         if kern:
             dom = max(kern, key=lambda k: kern[k]['total_ms'])
+            roof['traffic'] = pmc_traffic(dom)
             roof.update(kernel=dom, achieved=kern[dom]['tflops'], frac=kern[dom]['tflops'] / peak,
                         avg_launch_us=kern[dom]['avg_us'], flops_per_launch=kern[dom]['flops_per_launch'],
                         gemm_ms_per_step={k: v['total_ms'] / ksteps for k, v in kern.items()},

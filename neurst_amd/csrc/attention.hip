@@ -175,6 +175,18 @@ struct AttnArgs {
   int out_vec, dq_vec, dk_vec, dv_vec;   // 4 consecutive head columns may be stored as one vector
 };
 
+// XCD-aware block placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order, so the tiles that share one
+// (batch, head)'s K/V (or Q/dO) would land on 8 different L2s and fetch them 8 times over the fabric.  Give each XCD a
+// contiguous run of the flattened (tile, head, batch) index instead (bijective for any grid size).
+struct BlockId { int64_t x, y, z; };
+__device__ __forceinline__ BlockId remap_block() {
+  const int nx = gridDim.x, ny = gridDim.y, total = nx * ny * (int)gridDim.z;
+  const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  const int q = total >> 3, r = total & 7, xcd = lin & 7, loc = lin >> 3;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  return BlockId{id % nx, (id / nx) % ny, id / (nx * ny)};
+}
+
 // dropout decision for weight (row, col): row_base = flat index of the row's first weight
 __device__ __forceinline__ bool attn_keep(const AttnArgs& a, uint64_t row_base, int col) {
   if (a.idx32) return (fmix32(((uint32_t)row_base + (uint32_t)col) ^ a.inner0) >> 8) >= a.thr;
@@ -234,7 +246,8 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
   T* Ks = reinterpret_cast<T*>(smem);            // [64][LDK]
   T* Vs = Ks + 64 * LDK;                         // [64][LDK]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
-  const int64_t b = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * 64;
+  const BlockId bid = remap_block();
+  const int64_t b = bid.z, h = bid.y, q0 = bid.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
   const T* kg = reinterpret_cast<const T*>(a.k) + b * a.bsk + h * dh;
@@ -339,7 +352,8 @@ __global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArg
   T* Ks = reinterpret_cast<T*>(smem);             // [64][LDK]
   T* Vs = Ks + 64 * LDK;                          // [64][LDK]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
-  const int64_t b = blockIdx.z, h = blockIdx.y, q0 = (int64_t)blockIdx.x * 64;
+  const BlockId bid = remap_block();
+  const int64_t b = bid.z, h = bid.y, q0 = bid.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
   const T* kg = reinterpret_cast<const T*>(a.k) + b * a.bsk + h * dh;
@@ -446,7 +460,8 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
   float* lse_s = reinterpret_cast<float*>(dOs + 64 * LDK);  // [64]
   float* del_s = lse_s + 64;                          // [64]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
-  const int64_t b = blockIdx.z, h = blockIdx.y, kv0 = (int64_t)blockIdx.x * 64;
+  const BlockId bid = remap_block();
+  const int64_t b = bid.z, h = bid.y, kv0 = bid.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
   const T* kg = reinterpret_cast<const T*>(a.k) + b * a.bsk + h * dh;

@@ -138,6 +138,18 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias=None, relu=Fals
     return C
 
 
+def gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, split_k=1, bias_grad=False):
+    """Which instantiation of gemm_kernel (csrc/gemm.hip) a call runs - mirrors the host dispatch there; used by bench.py
+    to group its per-launch timings the way rocprofv3 groups kernels."""
+    ab = 'bf16' if A.dtype == torch.bfloat16 else 'f32'
+    c = 'bf16' if C.dtype == torch.bfloat16 else 'f32'
+    lay = {(False, True): 'NT', (False, False): 'NN', (True, False): 'TN', (True, True): 'TT'}[(bool(trans_a), bool(trans_b))]
+    fast = ab == 'bf16' and K % 8 == 0 and (not trans_a or M % 8 == 0) and (trans_b or N % 8 == 0)
+    tiles = -(-M // 128) * -(-N // 128) * max(split_k, 1)
+    ns = 4 if (fast and tiles <= 256 and K >= 256) else 2
+    return 'gemm_kernel<%s,%s,%s,%s,stages=%d%s>' % (ab, c, lay, 'direct-to-LDS' if fast else 'register-staged', ns, ',+bias-grad' if bias_grad else '')
+
+
 def gemm_wgrad_bias(A, B, C, opsum, sum_operand, M, N, K, lda, ldb, ldc, split_k=1):
     """C[M,N] += A^T.B (A [K,M], B [K,N]) and opsum += column sums of A (sum_operand 1) or B (2)."""
     _chk(L().neurst_gemm_wgrad_bias(_p(A), _p(B), _p(C), _p(opsum), sum_operand, M, N, K, lda, ldb, ldc, dt_of(A), split_k, _s()),

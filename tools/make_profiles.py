@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 output of one bench.py run (gpurun_out/<tag>/{stats,fetch,write}) into the committed summaries:
+  profiles/<tag>_bench_lut_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied verbatim)
+  profiles/<tag>_hbm_traffic.json             per-kernel HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B),
+                                              the gfx950 correction of MI355X_MICROARCH.md 'HBM', from two separate --pmc passes
+Usage: python tools/make_profiles.py r01"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gemm_label(name):
+    """mangled / half-demangled gemm_kernel<T, TC, TA, TB_KCONTIG, FAST, SUMOP, NS> -> the label bench.py uses"""
+    m = re.match(r'_Z11gemm_kernelI(DF16b|f)(DF16b|f)Lb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)EEv8GemmArgs', name)
+    if m:
+        t, tc, ta, tbk, fast, sumop, ns = m.groups()
+    else:
+        m = re.match(r'void gemm_kernel<bool _Accum, (true|false), (true|false), (true|false), (\d), (\d)>', name)
+        if not m:
+            return None
+        t, tc = 'DF16b', 'f'
+        ta, tbk, fast = ['1' if x == 'true' else '0' for x in m.groups()[:3]]
+        sumop, ns = m.groups()[3:]
+    lay = {('0', '1'): 'NT', ('0', '0'): 'NN', ('1', '0'): 'TN', ('1', '1'): 'TT'}[(ta, tbk)]
+    return 'gemm_kernel<%s,%s,%s,%s,stages=%s%s>' % ('bf16' if t == 'DF16b' else 'f32', 'bf16' if tc == 'DF16b' else 'f32', lay,
+                                                     'direct-to-LDS' if fast == '1' else 'register-staged', ns, ',+bias-grad' if sumop != '0' else '')
+
+
+def counters(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return d
+
+
+def main(tag):
+    src = os.path.join(ROOT, 'gpurun_out', tag)
+    dst = os.path.join(ROOT, 'profiles')
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, 'stats', 's_kernel_stats.csv'), os.path.join(dst, tag + '_bench_lut_kernel_stats.csv'))
+    f = counters(os.path.join(src, 'fetch', 'f_counter_collection.csv'))
+    w = counters(os.path.join(src, 'write', 'w_counter_collection.csv'))
+    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing',
+           'formula': 'bytes = 1000 * (2 * mean(FETCH_SIZE) + mean(WRITE_SIZE)); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B reads at 64 B); Infinity-Cache hits are included',
+           'bytes_per_launch': {}, 'raw_kernel_names': {}}
+    for k in sorted(f):
+        fb = sum(f[k]) / len(f[k])
+        wb = sum(w[k]) / len(w[k]) if k in w else 0.0
+        label = gemm_label(k) or k.split('(')[0]
+        out['bytes_per_launch'][label] = round(1000 * (2 * fb + wb))
+        out['raw_kernel_names'][label] = {'name': k, 'launches': len(f[k]), 'fetch_kb': round(fb, 1), 'write_kb': round(wb, 1)}
+    json.dump(out, open(os.path.join(dst, tag + '_hbm_traffic.json'), 'w'), indent=1)
+    print('wrote', os.listdir(dst))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r01')
