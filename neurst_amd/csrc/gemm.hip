@@ -321,6 +321,26 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   const T* rs = reinterpret_cast<const T*>(g.relu_src);
   const bool add_bias = g.bias && blockIdx.z == 0;
   const int64_t wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
+  // the columns a lane stores are the same in every pass: fetch its bias values once, ahead of the store loops
+  // (64 dependent scalar loads inside the loops used to cost more than the main loop of a K = 768 problem)
+  float bv[8], bsplit = 0.f;
+  {
+    const int64_t col = wcol0 + (lane & 7) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (add_bias) {
+      if (g.split_k > 1) {
+        if (wcol0 + lane < g.N) bsplit = g.bias[wcol0 + lane];
+      } else if (col + 8 <= g.N && (((uintptr_t)(g.bias + col)) & 15) == 0) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + col), b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (col + e < g.N) bv[e] = g.bias[col + e];
+      }
+    }
+  }
   if constexpr (SUMOP == 1) {   // D[m][n] = sum_k A[m][k] for every n: take column 0 (lanes 0,16,32,48)
     if (wn == 0 && (lane & 15) == 0) {
 #pragma unroll
@@ -356,8 +376,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
         for (int rr = 0; rr < 32; ++rr) {
           const int64_t row = wrow0 + half * 32 + rr;
           if (row < g.M && col < g.N) {
-            float v = Cs[rr * EPI_LD + lane];
-            if (add_bias) v += g.bias[col];
+            const float v = Cs[rr * EPI_LD + lane] + bsplit;
             atomicAdd(reinterpret_cast<float*>(C) + row * g.ldc + col, v);
           }
         }
@@ -378,10 +397,8 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
         const int64_t off = row * g.ldc + col;
         const bool full = g.c_vec && col + 8 <= g.N;
-        if (add_bias) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) if (col + e < g.N) v[e] += g.bias[col + e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
         if (g.relu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
