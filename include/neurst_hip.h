@@ -103,6 +103,22 @@ int neurst_mha_bwd(const void* q, const void* k, const void* v, const void* o, c
                    int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
                    int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
 
+/* Training variants of the two calls above that carry the attention-dropout decisions from forward to backward:
+ * keep_bits (neurst_mha_keep_bits_bytes(B,H,Tq,Tk) bytes, may be NULL = hash again in backward) receives, per
+ * 64x64 score tile, the 16-bit keep mask each forward thread computed; the backward kernels read it back instead of
+ * re-hashing.  Same results bit for bit (st/layers/common_attention_v1.py:357-359: TF keeps the mask tensor). */
+int64_t neurst_mha_keep_bits_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk);
+int neurst_mha_fwd_train(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits,
+                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                         int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
+int neurst_mha_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                         const float* lse, const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv,
+                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         int64_t lddq, int64_t lddk, int64_t lddv,
+                         int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                         int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
+
 /* a7 (+a6): out = LN(x + dropout(y)) * (t < len[b]) ; st/models/tools/utils.py:324-337,
  * st/layers/common_layers_v1.py:342-347 (eps 1e-6 inside rsqrt, biased variance).
  * z = x + dropout(y) is written over y (in place) for backward; mean/rstd [rows] fp32.

@@ -173,6 +173,10 @@ struct AttnArgs {
   float keep_scale, qscale;
   int q_aligned, k_aligned, v_aligned, o_aligned;
   int out_vec, dq_vec, dk_vec, dv_vec;   // 4 consecutive head columns may be stored as one vector
+  // optional [B*H][ceil(Tq/64)][ceil(Tk/64)][256] u16: the 16 dropout keep decisions each forward thread made for one tile;
+  // written by the forward, read back by both backward kernels instead of re-hashing 16 indices per thread and tile
+  uint16_t* keep_bits;
+  int nqt, nkt;
 };
 
 // XCD-aware block placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order, so the tiles that share one
@@ -311,6 +315,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
     m_run = mn;
     float lsum = 0.f;
     const uint32_t kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+    if (a.keep_bits && a.thr) a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid] = (uint16_t)kmask;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -407,7 +412,8 @@ __global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArg
       vreg.load(vg, a.ldv, kv0 + 64, a.Tk, dh, a.v_aligned, tid);
     }
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q_tail;
-    const uint32_t kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+    const uint32_t kmask = (a.keep_bits && a.thr) ? (uint32_t)a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid]
+                                                  : keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
     f32x4 ds[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -459,6 +465,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
   T* dOs = Qs + 64 * LDK;                             // [64][LDK]
   float* lse_s = reinterpret_cast<float*>(dOs + 64 * LDK);  // [64]
   float* del_s = lse_s + 64;                          // [64]
+  uint16_t* mask_s = reinterpret_cast<uint16_t*>(del_s + 64);   // [4][64]: the forward threads' keep bits of this (q tile, kv tile)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
   const BlockId bid = remap_block();
   const int64_t b = bid.z, h = bid.y, kv0 = bid.x * 64;
@@ -485,10 +492,14 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
 
   TileRegs<T, DH, FULL> qreg, doreg;
   float lse_reg = 0.f, del_reg = 0.f;   // threads 0..63: statistics of query q0 + tid of the staged tile
+  uint32_t mask_reg = 0;                // threads 64..191: two of the 256 stored keep masks of the tile
+  const bool stored = a.keep_bits && a.thr;
   auto load_stats = [&](int64_t q0n) {
     const int64_t qi = q0n + tid;
     if (tid < 64 && qi < a.Tq) { lse_reg = a.lse_in[bh * a.Tq + qi] * unit; del_reg = a.delta[bh * a.Tq + qi]; }
     else { lse_reg = 0.f; del_reg = 0.f; }
+    if (stored && tid >= 64 && tid < 192)
+      mask_reg = reinterpret_cast<const uint32_t*>(a.keep_bits + ((bh * a.nqt + (q0n >> 6)) * a.nkt + bid.x) * 256)[tid - 64];
   };
   if (q_begin < a.Tq) {
     qreg.load(qg, a.ldq, q_begin, a.Tq, dh, a.q_aligned, tid);
@@ -507,6 +518,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
     qreg.store(Qs, tid);
     doreg.store(dOs, tid);
     if (tid < 64) { lse_s[tid] = lse_reg; del_s[tid] = del_reg; }
+    else if (stored && tid < 192) reinterpret_cast<uint32_t*>(mask_s)[tid - 64] = mask_reg;
     __syncthreads();
 #if DKV_PREFETCH
     if (q0 + 64 < a.Tq) {
@@ -516,7 +528,21 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
     }
 #endif
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q0 + 64 > a.Tq;
-    const uint32_t kmask = keep_bits16(a, (uint64_t)((bh * a.Tq + q0) * a.Tk) + (uint64_t)kj, g4 * (int)a.Tk, 16 * (int)a.Tk, (int)a.Tk);
+    // weight (q = q0 + 16 nt + g4 + r, key kj): hashed here, or bit (4 w + (lane & 3)) of the mask the forward thread
+    // (wave nt, lane (g4 + r) + 16 ((lane & 15) >> 2)) stored - four neighbouring u16, one 8-byte LDS read per nt
+    uint32_t kmask;
+    if (stored) {
+      kmask = 0;
+      const int sh = 4 * w + (lane & 3);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint64_t m4 = *reinterpret_cast<const uint64_t*>(mask_s + nt * 64 + 16 * ((lane & 15) >> 2) + g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kmask |= (uint32_t)((m4 >> (16 * r + sh)) & 1u) << (nt * 4 + r);
+      }
+    } else {
+      kmask = keep_bits16(a, (uint64_t)((bh * a.Tq + q0) * a.Tk) + (uint64_t)kj, g4 * (int)a.Tk, 16 * (int)a.Tk, (int)a.Tk);
+    }
     // two halves of 32 queries: the probabilities of a half are consumed by the second products right away
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -580,7 +606,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
 // ================================================================== host side
 template <typename T, int DH> static size_t fwd_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
 template <typename T, int DH> static size_t dq_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
-template <typename T, int DH> static size_t dkv_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD) + 128 * sizeof(float); }
+template <typename T, int DH> static size_t dkv_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD) + 128 * sizeof(float) + 512; }
 
 template <typename K>
 static int launch_attn(K kernel, dim3 grid, size_t smem, const AttnArgs& a, hipStream_t s, const char* name) {
@@ -607,6 +633,7 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.dh = (int)dh; a.mask_mode = mask_mode; a.len_k = len_k;
   a.thr = rate > 0.f ? rate_threshold(rate) : 0u;
   a.key = key; a.keep_scale = keep_scale(rate);
+  a.nqt = (int)cdiv64(Tq, 64); a.nkt = (int)cdiv64(Tk, 64);
   a.inner0 = fmix32(key);   // == fmix32(hi ^ key) with hi == 0
   a.idx32 = (double)B * (double)H * (double)Tq * (double)Tk < 4294967296.0;
   a.qscale = 1.0f / sqrtf((float)dh);
@@ -632,13 +659,19 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
     else DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 192);                                               \
   } while (0)
 
-extern "C" int neurst_mha_fwd_strided(const void* q, const void* k, const void* v, void* o, float* lse, int64_t ldq, int64_t ldk,
-                                      int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t B, int64_t H,
-                                      int64_t Tq, int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key,
-                                      int dtype, void* stream) {
+extern "C" int64_t neurst_mha_keep_bits_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk) {
+  return B * H * cdiv64(Tq, 64) * cdiv64(Tk, 64) * 256 * (int64_t)sizeof(uint16_t);
+}
+
+static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits, int64_t ldq, int64_t ldk,
+                        int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t B, int64_t H,
+                        int64_t Tq, int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key,
+                        int dtype, void* stream) {
   NEURST_CHECK_ARG(q && k && v && o && lse, "mha_fwd: null pointer");
+  NEURST_CHECK_ARG(((uintptr_t)keep_bits & 3) == 0, "mha_fwd: keep_bits must be 4-byte aligned");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
+  a.keep_bits = keep_bits;
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
   int rc = fill_args(a, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype);
@@ -654,20 +687,47 @@ extern "C" int neurst_mha_fwd_strided(const void* q, const void* k, const void* 
   else DISPATCH_DH(float, mha_fwd_kernel, fwd_smem, grid, "mha_fwd");
   return rc;
 }
+extern "C" int neurst_mha_fwd_strided(const void* q, const void* k, const void* v, void* o, float* lse, int64_t ldq, int64_t ldk,
+                                      int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t B, int64_t H,
+                                      int64_t Tq, int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key,
+                                      int dtype, void* stream) {
+  return mha_fwd_impl(q, k, v, o, lse, nullptr, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype, stream);
+}
 extern "C" int neurst_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t ldq, int64_t ldk, int64_t ldv,
                               int64_t ldo, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh, int mask_mode,
                               const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream) {
-  return neurst_mha_fwd_strided(q, k, v, o, lse, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
-                                len_k, rate, key, dtype, stream);
+  return mha_fwd_impl(q, k, v, o, lse, nullptr, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
+                      len_k, rate, key, dtype, stream);
+}
+extern "C" int neurst_mha_fwd_train(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits, int64_t ldq,
+                                    int64_t ldk, int64_t ldv, int64_t ldo, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                                    int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream) {
+  return mha_fwd_impl(q, k, v, o, lse, keep_bits, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
+                      len_k, rate, key, dtype, stream);
 }
 
+extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                    const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv, int64_t ldq, int64_t ldk,
+                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq,
+                                    int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
+                                    void* stream);
 extern "C" int neurst_mha_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                               float* delta, void* dq, void* dk, void* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                               int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
                               int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream) {
+  return neurst_mha_bwd_train(q, k, v, o, d_o, lse, nullptr, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv, B, H, Tq, Tk, dh,
+                              mask_mode, len_k, rate, key, dtype, stream);
+}
+extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                    const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv, int64_t ldq, int64_t ldk,
+                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq,
+                                    int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
+                                    void* stream) {
   NEURST_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "mha_bwd: null pointer");
+  NEURST_CHECK_ARG(((uintptr_t)keep_bits & 3) == 0, "mha_bwd: keep_bits must be 4-byte aligned");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
+  a.keep_bits = const_cast<uint16_t*>(keep_bits);
   a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.lse_in = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   int rc = fill_args(a, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype);

@@ -173,18 +173,24 @@ def pick_split_k(M, N, K, n_cu=256):
 
 
 # ---- attention -------------------------------------------------------------------------
-def mha_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key):
+def mha_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, keep_bits=False):
+    """keep_bits=True (training with dropout): also returns the stored dropout decisions for mha_bwd."""
     o = torch.empty((B, Tq, H * dh), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+    if keep_bits:
+        kb = torch.empty(L().neurst_mha_keep_bits_bytes(B, H, Tq, Tk) // 2, dtype=torch.int16, device=q.device) if rate > 0 else None
+        _chk(L().neurst_mha_fwd_train(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(kb), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode,
+                                      _p(len_k), rate, key, dt_of(q), _s()), 'mha_fwd_train')
+        return o, lse, kb
     _chk(L().neurst_mha_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key,
                             dt_of(q), _s()), 'mha_fwd')
     return o, lse
 
 
-def mha_bwd(q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key):
+def mha_bwd(q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, keep_bits=None):
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
-    _chk(L().neurst_mha_bwd(_p(q), _p(k), _p(v), _p(o), _p(_c(d_o)), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), ldq, ldk, ldv, H * dh,
-                            lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key, dt_of(q), _s()), 'mha_bwd')
+    _chk(L().neurst_mha_bwd_train(_p(q), _p(k), _p(v), _p(o), _p(_c(d_o)), _p(lse), _p(keep_bits), _p(delta), _p(dq), _p(dk), _p(dv), ldq, ldk,
+                                  ldv, H * dh, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key, dt_of(q), _s()), 'mha_bwd')
 
 
 # ---- layer norm ------------------------------------------------------------------------

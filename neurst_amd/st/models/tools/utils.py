@@ -158,8 +158,12 @@ def multihead_attention(query_antecedent, memory_antecedent, bias, total_key_dep
             k = (kvbuf, 0, 2 * d)
             v = (kvbuf, d, 2 * d)
         view = lambda t: t[0].view(-1)[t[1]:]       # pointer to the first element of the (strided) operand
-        x, lse = ops.mha_fwd(view(q), view(k), view(v), q[2], k[2], v[2], B, H, Tq, Tk, dh, mode, lens, rate, key)
         tape = g.tape
+        if tape is not None:   # training: keep the dropout decisions for backward (the TF graph keeps the mask tensor)
+            x, lse, kb = ops.mha_fwd(view(q), view(k), view(v), q[2], k[2], v[2], B, H, Tq, Tk, dh, mode, lens, rate, key, keep_bits=True)
+        else:
+            x, lse = ops.mha_fwd(view(q), view(k), view(v), q[2], k[2], v[2], B, H, Tq, Tk, dh, mode, lens, rate, key)
+            kb = None
         if tape is not None:
             def bwd():
                 dx = tape.pop(x)
@@ -169,12 +173,12 @@ def multihead_attention(query_antecedent, memory_antecedent, bias, total_key_dep
                     dcomb = torch.empty_like(combined)
                     dq, dk, dv = dcomb.view(-1), dcomb.view(-1)[d:], dcomb.view(-1)[2 * d:]
                     ops.mha_bwd(view(q), view(k), view(v), x, dx, lse, dq, dk, dv, q[2], k[2], v[2], 3 * d, 3 * d, 3 * d,
-                                B, H, Tq, Tk, dh, mode, lens, rate, key)
+                                B, H, Tq, Tk, dh, mode, lens, rate, key, keep_bits=kb)
                     tape.set(combined, dcomb)
                 else:
                     dqb, dkvb = torch.empty_like(qbuf), torch.empty_like(kvbuf)
                     ops.mha_bwd(view(q), view(k), view(v), x, dx, lse, dqb.view(-1), dkvb.view(-1), dkvb.view(-1)[d:], q[2], k[2], v[2],
-                                d, 2 * d, 2 * d, B, H, Tq, Tk, dh, mode, lens, rate, key)
+                                d, 2 * d, 2 * d, B, H, Tq, Tk, dh, mode, lens, rate, key, keep_bits=kb)
                     tape.set(qbuf, dqb)
                     tape.set(kvbuf, dkvb)
             tape.push(bwd)

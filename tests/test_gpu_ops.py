@@ -199,9 +199,13 @@ ATT_CASES = [
 ]
 
 
+@pytest.mark.parametrize('stored', [False, True])
 @pytest.mark.parametrize('dtype,tol', [('f32', 2e-5), ('bf16', 3e-2)])
 @pytest.mark.parametrize('B,H,Tq,Tk,dh,mode,rate', ATT_CASES)
-def test_attention_fwd_bwd(dtype, tol, B, H, Tq, Tk, dh, mode, rate):
+def test_attention_fwd_bwd(dtype, tol, B, H, Tq, Tk, dh, mode, rate, stored):
+    """stored: the dropout decisions travel from forward to backward as bit masks instead of being hashed again"""
+    if stored and rate == 0.0:
+        pytest.skip('no dropout: nothing to store')
     rng = np.random.default_rng(Tq * 7 + dh)
     td = torch.float32 if dtype == 'f32' else torch.bfloat16
     d = H * dh
@@ -218,10 +222,14 @@ def test_attention_fwd_bwd(dtype, tol, B, H, Tq, Tk, dh, mode, rate):
     dq_r, dk_r, dv_r = O.mha_core_bwd(do.astype(np.float64), cache)
     qd, kd, vd = dev(q, td), dev(k, td), dev(v, td)
     ld = dev(lens) if mode == 'keypad' else None
-    o, lse = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key)
+    kb = None
+    if stored:
+        o, lse, kb = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=True)
+    else:
+        o, lse = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key)
     assert relerr(host(o), ref) < tol
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    ops.mha_bwd(qd, kd, vd, o, dev(do, td), lse, dq, dk, dv, d, d, d, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key)
+    ops.mha_bwd(qd, kd, vd, o, dev(do, td), lse, dq, dk, dv, d, d, d, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=kb)
     assert relerr(host(dq), dq_r) < tol and relerr(host(dk), dk_r) < tol and relerr(host(dv), dv_r) < tol
 
 

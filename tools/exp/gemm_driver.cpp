@@ -17,7 +17,12 @@ int main(int argc, char** argv) {
       {"enc qkv NT", 16000, 2304, 768, 0, 1, 0, 1},   {"enc ffn1 NT", 16000, 3072, 768, 0, 1, 0, 1},
       {"enc ffn2 NT", 16000, 768, 3072, 0, 1, 0, 1},  {"enc out NT", 16000, 768, 768, 0, 1, 0, 1},
       {"enc dgrad NN", 16000, 768, 2304, 0, 0, 0, 1}, {"enc wgrad ffn1 TN s3", 3072, 768, 16000, 1, 0, 1, 3},
-      {"enc wgrad out TN s6", 768, 768, 16000, 1, 0, 1, 6},
+      {"enc wgrad out TN s6", 768, 768, 16000, 1, 0, 1, 6},   {"enc wgrad out TN s8", 768, 768, 16000, 1, 0, 1, 8},
+      {"enc wgrad out TN s12", 768, 768, 16000, 1, 0, 1, 12},
+      {"dec wgrad TN s2", 768, 768, 1280, 1, 0, 1, 2},        {"dec wgrad TN s4", 768, 768, 1280, 1, 0, 1, 4},
+      {"dec wgrad qkv TN s1", 2304, 768, 1280, 1, 0, 1, 1},   {"dec wgrad qkv TN s2", 2304, 768, 1280, 1, 0, 1, 2},
+      {"dec wgrad ffn TN s2", 3072, 768, 1280, 1, 0, 1, 2},   {"dec wgrad ffn TN s4", 3072, 768, 1280, 1, 0, 1, 4},
+      {"dec wgrad fc TN s1", 768, 10000, 1280, 1, 0, 1, 1},   {"dec wgrad fc TN s2", 768, 10000, 1280, 1, 0, 1, 2},
   };
   size_t maxe = 16000ull * 10000;
   void *A, *B, *C; float* bias;
