@@ -44,7 +44,7 @@ def load_config(config_files):
     return cfg
 
 
-def build_args(config, dim_output, token2idx=None, dim_feature=None, compute_dtype='bf16', seed=0, overrides=None):
+def build_args(config, dim_output, token2idx=None, dim_feature=None, compute_dtype=None, seed=0, overrides=None):
     """`config`: path(s) of YAML file(s) or an already loaded dict.  Returns the `args`
     AttrDict the model classes read, with the derived fields of arguments.py:48-49,77-100,
     111-121,216-272,304-307."""
@@ -88,6 +88,6 @@ def build_args(config, dim_output, token2idx=None, dim_feature=None, compute_dty
         raise NotImplementedError('only model.structure == transformerTpe is on the hot path (got {})'.format(m.structure))
     args.Model = TransformerTPE
     # build-side extensions (absent from the reference schema)
-    args.compute_dtype = args.compute_dtype or compute_dtype
+    args.compute_dtype = compute_dtype or args.compute_dtype or 'bf16'      # an explicit argument wins over the YAML key
     args.seed = args.seed if args.seed is not None else seed
     return args
