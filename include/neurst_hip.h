@@ -128,7 +128,8 @@ int neurst_dropout_add_layernorm_fwd(const void* x, void* y_inout_z, const float
                                      float rate, uint32_t key, const int32_t* lens, int64_t T,
                                      int dtype, void* stream);
 /* dz (gradient wrt x, and wrt y when rate==0) and dy = dz*mask*scale (dy may be NULL or == dz
- * when rate == 0); dgamma/dbeta accumulate (+=) in fp32; partial [2*nblk*C] fp32 workspace
+ * when rate == 0); dgamma/dbeta accumulate (+=) in fp32; partial: NULL = workgroups add their column partials to dgamma/dbeta with fp32 atomics (fast, summation order
+ * varies); or a [2*nblk*C] fp32 workspace = deterministic two-pass reduction
  * where nblk = neurst_layernorm_bwd_blocks(rows). */
 int64_t neurst_layernorm_bwd_blocks(int64_t rows);
 int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z, const float* gamma,

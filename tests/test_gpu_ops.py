@@ -186,6 +186,9 @@ def test_dropout_add_layernorm(dtype, tol, C, rate):
     dz, dy = ops.dropout_add_layernorm_bwd(dev(dout, td), yz, dev(gam), mean, rstd, dg, db, rate, key, dev(lens), T)
     assert relerr(host(dz), dz_ref) < tol and relerr(host(dy), dy_ref) < tol
     assert relerr(host(dg), dg_ref) < tol and relerr(host(db), db_ref) < tol
+    dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)      # two-pass (deterministic) column sums
+    ops.dropout_add_layernorm_bwd(dev(dout, td), yz, dev(gam), mean, rstd, dg2, db2, rate, key, dev(lens), T, deterministic=True)
+    assert relerr(host(dg2), dg_ref) < tol and relerr(host(db2), db_ref) < tol
 
 
 ATT_CASES = [
