@@ -43,9 +43,9 @@ __device__ __forceinline__ typename Chunk<T>::V load_chunk(const T* __restrict__
 // bf16 tiles are unpadded and XOR-swizzled at 16-byte granularity so that both ds_read_b128 row reads
 // (128-B rows: chunk ^= row&7) and ds_read_b64_tr_b16 (256-B rows: chunk ^= ((row&3)<<2)|((row>>2)&3),
 // cdna_hip_programming.md T10 image (b)) are bank-conflict free; fp32 (parity mode) tiles are padded.
-template <typename T, bool TRANS>
+template <typename T, bool TRANS, int BKT = GemmCfg<T>::BK>
 struct Stager {
-  static constexpr int BK = GemmCfg<T>::BK, EPC = GemmCfg<T>::EPC;
+  static constexpr int BK = BKT, EPC = GemmCfg<T>::EPC;
   static constexpr bool SWZ = sizeof(T) == 2;
   static constexpr int LD = SWZ ? (TRANS ? 128 : BK) : (TRANS ? GemmCfg<T>::LDT : GemmCfg<T>::LDK);
   static constexpr int TILE = (TRANS ? BK : 128) * LD;   // elements
@@ -54,9 +54,12 @@ struct Stager {
   typename Chunk<T>::V reg[NCH];
 
   // element offset of 16-byte chunk `ch` of LDS row `r`
+  // K-contiguous tiles: 128-B rows (BK = 64) spread a read group over the 8 chunk slots with r & 7; 64-B rows (BK = 32)
+  // alias every 4 rows and use the 4 slots per row with (-(r >> 2)) & 3
+  static __device__ __forceinline__ int kswz(int r) { return BK == 64 ? (r & 7) : ((0 - (r >> 2)) & 3); }
   static __device__ __forceinline__ int off(int r, int ch) {
     if constexpr (!SWZ) return r * LD + ch * EPC;
-    else if constexpr (!TRANS) return r * LD + ((ch ^ (r & 7)) << 3);
+    else if constexpr (!TRANS) return r * LD + ((ch ^ kswz(r)) << 3);
     else return r * LD + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 3);
   }
   __device__ __forceinline__ void load(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R, int64_t Kend,
@@ -115,16 +118,16 @@ template <> __device__ __forceinline__ bf16x8 ones_frag<bf16_t>() {
 // applied to the SOURCE chunk each lane fetches (cdna_hip_programming.md 5.4 rule 21).  Rows of the
 // output dimension beyond R are clamped to a valid address: they only feed output rows/columns that the
 // epilogue never stores.  The reduction range of the tile must be fully in bounds.
-template <typename T, bool TRANS>
+template <typename T, bool TRANS, int BKT>
 __device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R,
                                            T* __restrict__ S, int tid) {
-  typedef Stager<T, TRANS> St;
+  typedef Stager<T, TRANS, BKT> St;
 #pragma unroll
   for (int i = 0; i < St::NCH; ++i) {
     const int P = tid + i * NT;                      // 16-byte chunk position in the LDS tile
     const int r = P / St::CPR, cpos = P % St::CPR;
     int c;                                           // source chunk that belongs at this position
-    if constexpr (!TRANS) c = cpos ^ (r & 7);
+    if constexpr (!TRANS) c = cpos ^ St::kswz(r);
     else c = cpos ^ (((r & 3) << 2) | ((r >> 2) & 3));
     const T* src;
     if constexpr (!TRANS) {
@@ -144,7 +147,7 @@ __device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t l
 template <typename T, typename SA, typename SB, int SUMOP>
 __device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __restrict__ Bc, f32x4 (&acc)[4][4], f32x4 (&sacc)[4], bool duty,
                                          int wm, int wn, int lane) {
-  constexpr int BK = GemmCfg<T>::BK, KS = Mma<T>::KS;
+  constexpr int BK = SA::BK, KS = Mma<T>::KS;
   typename Mma<T>::Frag sel = ones_frag<T>();
   if (!duty) sel = sel - sel;
 #pragma unroll
@@ -179,9 +182,11 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
   // FAST (bf16, aligned operands): full K-tiles go global -> LDS directly (no VGPR staging).
   // NS = LDS stages.  2: three workgroups per CU hide each other's load latency (large grids).  4: for grids of at most
   // one workgroup per CU - three K-tiles (96 KB) stay in flight per CU across raw barriers with counted vmcnt waits.
-  constexpr int BK = GemmCfg<T>::BK;
-  typedef Stager<T, TA> SA;
-  typedef Stager<T, !TB_KCONTIG> SB;
+  // K-tile depth: 64 (bf16), except NN (A K-contiguous, B k-strided) where 32 measured 3-14 % faster on the LUT shapes
+  // (NT, TN and the 4-stage small-grid variant lose 5-25 % at 32); 16 for fp32
+  constexpr int BK = (sizeof(T) == 2 && !TA && !TB_KCONTIG && NS == 2) ? 32 : GemmCfg<T>::BK;
+  typedef Stager<T, TA, BK> SA;
+  typedef Stager<T, !TB_KCONTIG, BK> SB;
   constexpr int STAGE_BYTES = NS * (SA::TILE + SB::TILE) * (int)sizeof(T);
   constexpr int SMEM = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];   // ONE LDS object (staging ring, then epilogue tiles)
@@ -235,15 +240,15 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
     const int nfull = (int)((kend - kbeg) / BK);
     if constexpr (NS == 2) {
       if (nfull > 0) {
-        issue_glds<T, TA>(A, g.lda, m0, kbeg, g.M, As(0), tid);
-        issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kbeg, g.N, Bs(0), tid);
+        issue_glds<T, TA, BK>(A, g.lda, m0, kbeg, g.M, As(0), tid);
+        issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kbeg, g.N, Bs(0), tid);
       }
       for (int it = 0; it < nfull; ++it) {
         __syncthreads();   // tile `it` has landed (vmcnt(0) precedes the barrier) and buf[cur^1] is no longer read
         if (it + 1 < nfull) {
           const int64_t kn = kbeg + (int64_t)(it + 1) * BK;
-          issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
-          issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
+          issue_glds<T, TA, BK>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
+          issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
         }
         mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(kbeg + (int64_t)it * BK), wm, wn, lane);
         cur ^= 1;
@@ -255,8 +260,8 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
       static_assert(LPT * (NS - 2) <= 63, "vmcnt field");
       const int npro = nfull < NS - 1 ? nfull : NS - 1;
       for (int t = 0; t < npro; ++t) {
-        issue_glds<T, TA>(A, g.lda, m0, kbeg + (int64_t)t * BK, g.M, As(t), tid);
-        issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kbeg + (int64_t)t * BK, g.N, Bs(t), tid);
+        issue_glds<T, TA, BK>(A, g.lda, m0, kbeg + (int64_t)t * BK, g.M, As(t), tid);
+        issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kbeg + (int64_t)t * BK, g.N, Bs(t), tid);
       }
       for (int it = 0; it < nfull; ++it) {
         const int issued = it + NS - 1 < nfull ? it + NS - 1 : nfull;
@@ -269,8 +274,8 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
         if (it + NS - 1 < nfull) {
           const int nb = (cur + NS - 1) % NS;
           const int64_t kn = kbeg + (int64_t)(it + NS - 1) * BK;
-          issue_glds<T, TA>(A, g.lda, m0, kn, g.M, As(nb), tid);
-          issue_glds<T, !TB_KCONTIG>(B, g.ldb, n0, kn, g.N, Bs(nb), tid);
+          issue_glds<T, TA, BK>(A, g.lda, m0, kn, g.M, As(nb), tid);
+          issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kn, g.N, Bs(nb), tid);
         }
         mma_tile<T, SA, SB, SUMOP>(As(cur), Bs(cur), acc, sacc, duty(kbeg + (int64_t)it * BK), wm, wn, lane);
         cur = (cur + 1) % NS;

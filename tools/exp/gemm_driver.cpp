@@ -16,7 +16,11 @@ int main(int argc, char** argv) {
       {"dec wgrad TN", 768, 768, 1280, 1, 0, 1, 1},   {"dec wgrad ffn TN", 3072, 768, 1280, 1, 0, 1, 1},
       {"enc qkv NT", 16000, 2304, 768, 0, 1, 0, 1},   {"enc ffn1 NT", 16000, 3072, 768, 0, 1, 0, 1},
       {"enc ffn2 NT", 16000, 768, 3072, 0, 1, 0, 1},  {"enc out NT", 16000, 768, 768, 0, 1, 0, 1},
-      {"enc dgrad NN", 16000, 768, 2304, 0, 0, 0, 1}, {"enc wgrad ffn1 TN s3", 3072, 768, 16000, 1, 0, 1, 3},
+      {"enc dgrad NN", 16000, 768, 2304, 0, 0, 0, 1},
+      {"enc dgrad ffn2 NN", 16000, 3072, 768, 0, 0, 0, 1},    {"enc dgrad ffn1 NN", 16000, 768, 3072, 0, 0, 0, 1},
+      {"enc dgrad out NN", 16000, 768, 768, 0, 0, 0, 1},      {"ctc head NN f32", 16000, 10000, 768, 0, 0, 1, 1},
+      {"dec kv NT", 16000, 1536, 768, 0, 1, 0, 1},            {"dgrad ctc NT", 16000, 768, 10000, 0, 1, 0, 1},
+      {"enc wgrad qkv TN s4", 2304, 768, 16000, 1, 0, 1, 4},  {"wgrad ctc TN", 768, 10000, 16000, 1, 0, 1, 1}, {"enc wgrad ffn1 TN s3", 3072, 768, 16000, 1, 0, 1, 3},
       {"enc wgrad out TN s6", 768, 768, 16000, 1, 0, 1, 6},   {"enc wgrad out TN s8", 768, 768, 16000, 1, 0, 1, 8},
       {"enc wgrad out TN s12", 768, 768, 16000, 1, 0, 1, 12},
       {"dec wgrad TN s2", 768, 768, 1280, 1, 0, 1, 2},        {"dec wgrad TN s4", 768, 768, 1280, 1, 0, 1, 4},
