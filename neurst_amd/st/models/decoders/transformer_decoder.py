@@ -74,7 +74,8 @@ class Transformer_Decoder(Decoder):
         cur = torch.full((B, 1), int(self.start_token), dtype=torch.int32, device=dev)   # token fed at this step
         finished = torch.zeros(B, dtype=torch.int32, device=dev)
         len_decoded = torch.ones(B, dtype=torch.int32, device=dev)
-        n_unfinished = torch.zeros(1, dtype=torch.int32, device=dev)
+        unfinished_hist = torch.zeros(max_steps, dtype=torch.int32, device=dev)   # rows still decoding after each step
+        CHECK_EVERY = 8      # host looks at the stop condition every 8 steps (one read back), not every step
         kv_cache = [torch.empty((B, max_steps, 2 * d), dtype=tdt, device=dev) for _ in range(self.num_blocks)]
         mem_kv = []
         for i in range(self.num_blocks):   # encoder-side K/V of every block, once
@@ -106,12 +107,16 @@ class Transformer_Decoder(Decoder):
                     x = residual(x, ff_hidden(x, hidden_size=4 * d, output_size=d, activation='relu'), 0.0)
                     g.name_counts = {}   # the same layer_norm / ff_hidden names are reused every step
             cur_logit = tf_layers_dense(x.view(B, d), self.dim_output, use_bias=False, name='decoder_fc', out_dtype=ops.F32)
-            n_unfinished.zero_()
-            ops.greedy_step(cur_logit, preds, finished, len_decoded, n_unfinished, step, self.end_token)
+            ops.greedy_step(cur_logit, preds, finished, len_decoded, unfinished_hist[step:step + 1], step, self.end_token)
             cur.copy_(preds[:, step:step + 1])
             step += 1
-            if int(n_unfinished.item()) == 0:     # tf.reduce_any(not finished) - one 4-byte read back per step
-                break
+            # tf.reduce_any(not finished): the loop ends after the first step that leaves no row unfinished.  Steps run
+            # past that point (at most CHECK_EVERY - 1) only touch finished rows and are trimmed below.
+            if step % CHECK_EVERY == 0 or step == max_steps:
+                done = np.nonzero(unfinished_hist[:step].cpu().numpy() == 0)[0]
+                if done.size:
+                    step = int(done[0]) + 1
+                    break
         fin = finished.cpu().numpy()
         ld = len_decoded.cpu().numpy() - (1 - fin)        # "for decoded length cut by encoded length" (:115)
         out = preds[:, :step].cpu().numpy()
