@@ -171,6 +171,13 @@ int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_logits, cons
                             const int32_t* len_labels, float* loss, void* grad, int grad_dtype,
                             int32_t* argmax, void* workspace, int64_t B, int64_t T, int64_t V,
                             int64_t Umax, float grad_scale, void* stream);
+/* The same in two parts that may be issued on different streams: phases 1 = per-frame softmax / arg-max / gathered
+ * log-probabilities (everything a13's shrink layer waits for), 2 = alpha-beta recursion + sparse gradient correction
+ * (needs part 1 complete), 3 = both. */
+int neurst_ctc_loss_fwd_bwd_phased(const float* logits, const int32_t* len_logits, const int32_t* labels,
+                                   const int32_t* len_labels, float* loss, void* grad, int grad_dtype,
+                                   int32_t* argmax, void* workspace, int64_t B, int64_t T, int64_t V,
+                                   int64_t Umax, float grad_scale, int phases, void* stream);
 /* per-frame argmax only (inference path of a12/a13). */
 int neurst_argmax_rows(const float* logits, int32_t* argmax, int64_t rows, int64_t V, void* stream);
 /* a12: tf.nn.ctc_greedy_decoder(merge_repeated=True) + sparse_to_dense(default 0),

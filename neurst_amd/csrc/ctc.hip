@@ -312,9 +312,13 @@ __global__ void ctc_grad_fix_kernel(const int32_t* __restrict__ len_logits, CtcW
   }
 }
 
-extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_logits, const int32_t* labels, const int32_t* len_labels,
-                                       float* loss, void* grad, int grad_dtype, int32_t* argmax, void* workspace, int64_t B, int64_t T,
-                                       int64_t V, int64_t Umax, float grad_scale, void* stream) {
+// phases: 1 = per-frame part (softmax as gradient base, arg-max, gathered log-probabilities), 2 = alpha-beta recursion and
+// the sparse gradient correction; 3 = both.  Phase 2 may run on another stream once phase 1 has finished there.
+extern "C" int neurst_ctc_loss_fwd_bwd_phased(const float* logits, const int32_t* len_logits, const int32_t* labels,
+                                              const int32_t* len_labels, float* loss, void* grad, int grad_dtype, int32_t* argmax,
+                                              void* workspace, int64_t B, int64_t T, int64_t V, int64_t Umax, float grad_scale,
+                                              int phases, void* stream) {
+  NEURST_CHECK_ARG(phases >= 1 && phases <= 3, "ctc: phases must be 1, 2 or 3");
   NEURST_CHECK_ARG(logits && len_logits && labels && len_labels && loss && grad && workspace, "ctc: null pointer");
   NEURST_CHECK_ARG(B > 0 && T > 0 && V > 1 && Umax > 0, "ctc: bad shape");
   const int64_t Smax = 2 * Umax + 1;
@@ -322,6 +326,7 @@ extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_l
   NEURST_CHECK_ARG(grad_dtype == NEURST_F32 || (const void*)grad != (const void*)logits, "ctc: bf16 gradient cannot alias the logits");
   hipStream_t s = as_stream(stream);
   CtcWs w = carve_ws(workspace, B, T, Smax);
+  if (phases & 1) {
   ctc_prep_kernel<<<(int)B, 128, 0, s>>>(labels, len_labels, len_logits, w, Umax, Smax, T, (int)V);
   NEURST_CHECK_LAUNCH("ctc_prep");
   const int use_cache = V * sizeof(float) <= 64 * 1024;
@@ -340,6 +345,8 @@ extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_l
     ctc_frame_kernel<float><<<nblk, 256, shm, s>>>(logits, len_logits, w, (float*)grad, argmax, T, (int)V, Smax, grad_scale, use_cache);
 #undef CTC_FRAME_REG
   NEURST_CHECK_LAUNCH("ctc_frame");
+  }
+  if (!(phases & 2)) return NEURST_OK;
   int nthr = (int)((Smax + 63) / 64 * 64);
   ctc_alpha_beta_kernel<<<(int)B, nthr, 2 * (Smax + 4) * sizeof(double), s>>>(len_logits, w, loss, T, Smax);
   NEURST_CHECK_LAUNCH("ctc_alpha_beta");
@@ -349,6 +356,12 @@ extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_l
     ctc_grad_fix_kernel<float><<<(unsigned)(B * T), 128, 0, s>>>(len_logits, w, (float*)grad, T, (int)V, Smax, grad_scale);
   NEURST_CHECK_LAUNCH("ctc_grad_fix");
   return NEURST_OK;
+}
+extern "C" int neurst_ctc_loss_fwd_bwd(const float* logits, const int32_t* len_logits, const int32_t* labels, const int32_t* len_labels,
+                                       float* loss, void* grad, int grad_dtype, int32_t* argmax, void* workspace, int64_t B, int64_t T,
+                                       int64_t V, int64_t Umax, float grad_scale, void* stream) {
+  return neurst_ctc_loss_fwd_bwd_phased(logits, len_logits, labels, len_labels, loss, grad, grad_dtype, argmax, workspace, B, T, V, Umax,
+                                        grad_scale, 3, stream);
 }
 
 // ---- per-row first-maximum argmax (inference)

@@ -252,15 +252,27 @@ def embedding_bwd(ids, dout, dtable, rate, key):
 
 
 # ---- CTC / greedy / shrink -------------------------------------------------------------------
-def ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, grad_dtype, grad_scale, in_place=False):
+def ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, grad_dtype, grad_scale, in_place=False, recursion_stream=None):
+    """recursion_stream: run the alpha-beta recursion and the gradient correction there (after the per-frame part on the
+    current stream): arg-max is then available on the current stream right away, loss / grad once that stream is joined."""
     B, T, V = logits.shape
     Umax = labels.shape[1]
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     grad = logits if (in_place and grad_dtype == F32) else torch.empty((B, T, V), dtype=torch_dtype(grad_dtype), device=logits.device)
     argmax = torch.empty((B, T), dtype=torch.int32, device=logits.device)
     ws = torch.empty(L().neurst_ctc_workspace_bytes(B, T, Umax), dtype=torch.uint8, device=logits.device)
-    _chk(L().neurst_ctc_loss_fwd_bwd(_p(_c(logits)), _p(len_logits), _p(_c(labels)), _p(len_labels), _p(loss), _p(grad), grad_dtype, _p(argmax),
-                                     _p(ws), B, T, V, Umax, grad_scale, _s()), 'ctc_loss_fwd_bwd')
+    labels = _c(labels)
+    args = (_p(_c(logits)), _p(len_logits), _p(labels), _p(len_labels), _p(loss), _p(grad), grad_dtype, _p(argmax), _p(ws), B, T, V, Umax,
+            grad_scale)
+    if recursion_stream is None:
+        _chk(L().neurst_ctc_loss_fwd_bwd_phased(*args, 3, _s()), 'ctc_loss_fwd_bwd')
+        return loss, grad, argmax
+    _chk(L().neurst_ctc_loss_fwd_bwd_phased(*args, 1, _s()), 'ctc_loss_fwd_bwd(frames)')
+    recursion_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(recursion_stream):
+        _chk(L().neurst_ctc_loss_fwd_bwd_phased(*args, 2, _s()), 'ctc_loss_fwd_bwd(recursion)')
+    for t in (ws, loss, grad, labels, len_logits, len_labels):   # allocated on the current stream, still in use on the other one
+        t.record_stream(recursion_stream)
     return loss, grad, argmax
 
 

@@ -157,11 +157,12 @@ class TransformerTPE(Seq2SeqModel):
         self.decoder_ctc = self.ctc_decoder(is_train=self.is_train, embed_table=self.src_embed_table, global_step=self.global_step, args=a)
 
     # ------------------------------------------------------------------ pieces of build_single_graph
-    def ctc_loss(self, logits, len_logits, labels, len_labels, grad_scale=1.0):
+    def ctc_loss(self, logits, len_logits, labels, len_labels, grad_scale=1.0, recursion_stream=None):
         """tf.nn.ctc_loss(..., ctc_merge_repeated=True, ignore_longer_outputs_than_inputs=True) (:93-102).
         Returns (loss [B], argmax [B,T]) and registers the gradient wrt logits on the tape."""
         g = self.graph
-        loss, grad, argmax = ops.ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, g.dtype, grad_scale, in_place=(g.dtype == ops.F32))
+        loss, grad, argmax = ops.ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, g.dtype, grad_scale, in_place=(g.dtype == ops.F32),
+                                                  recursion_stream=recursion_stream)
         if g.tape is not None:
             g.tape.set(logits, grad)
         return loss, argmax
@@ -230,8 +231,15 @@ class TransformerTPE(Seq2SeqModel):
                     preds_am, len_preds_am = self.ctc_decode(argmax_am, len_logits_am)
                 self._ctc_pending = True
             else:
+                # shrink_layer needs the arg-max now: only the recursion and the gradient correction leave the main stream
+                rs = None
+                if logits_am.is_cuda:
+                    if self._ctc_stream is None:
+                        self._ctc_stream = torch.cuda.Stream(device=self.device)
+                    rs = self._ctc_stream
                 loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],
-                                                    len_labels=batch['len_aux_label'], grad_scale=ctc_scale)
+                                                    len_labels=batch['len_aux_label'], grad_scale=ctc_scale, recursion_stream=rs)
+                self._ctc_pending = rs is not None
         else:
             B, T, V = logits_am.shape
             argmax_am = ops.argmax_rows(logits_am.view(B * T, V)).view(B, T)
