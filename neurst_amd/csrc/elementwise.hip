@@ -62,7 +62,7 @@ extern "C" int neurst_splice_downsample(const float* x, const int32_t* len_raw, 
 
 // ---------------------------------------------------------------- a3
 // one block per utterance: count non-zero frames, then draw the 8 parameters
-__global__ void specaug_params_kernel(const float* __restrict__ x, int32_t* __restrict__ params, int64_t T, int64_t v,
+__global__ void __launch_bounds__(1024) specaug_params_kernel(const float* __restrict__ x, int32_t* __restrict__ params, int64_t T, int64_t v,
                                       int F, int Tmax, float p, uint32_t key) {
   __shared__ float red[16];
   const int64_t b = blockIdx.x;
@@ -112,7 +112,7 @@ __global__ void specaug_apply_kernel(float* __restrict__ x, const int32_t* __res
 extern "C" int neurst_specaug_params(const float* x, int32_t* params, int64_t B, int64_t T, int64_t v, int F, int Tmax,
                                      float p, uint32_t key, void* stream) {
   NEURST_CHECK_ARG(B > 0 && T > 0 && v > 0 && F >= 1 && Tmax >= 1, "specaug_params: bad shape");
-  specaug_params_kernel<<<(int)B, 256, 0, as_stream(stream)>>>(x, params, T, v, F, Tmax, p, key);
+  specaug_params_kernel<<<(int)B, 1024, 0, as_stream(stream)>>>(x, params, T, v, F, Tmax, p, key);   // 16 waves share one utterance's frames
   NEURST_CHECK_LAUNCH("specaug_params");
   return NEURST_OK;
 }
