@@ -48,7 +48,8 @@ def pmc_traffic(kernel_label):
 
 
 class KernelTimer:
-    """HIP-event timing of individual launches on the stream they are issued on (the torch current stream)."""
+    """HIP-event timing of individual launches on the stream they are issued on (ops.active_stream(): the torch
+    current stream, or the side stream small weight gradients are routed to)."""
 
     def __init__(self):
         self.records = {}
@@ -63,9 +64,10 @@ class KernelTimer:
                 return orig(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw)
             name = ops.gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, kw.get('split_k', 1))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            st = ops.active_stream()
+            e0.record(st)
             r = orig(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, **kw)
-            e1.record()
+            e1.record(st)
             timer.records.setdefault(name, []).append((e0, e1, 2.0 * M * N * K))
             return r
         ops.gemm = gemm
@@ -75,9 +77,10 @@ class KernelTimer:
             if not timer.enabled:
                 return orig_w(A, B, C, opsum, which, M, N, K, lda, ldb, ldc, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            st = ops.active_stream()
+            e0.record(st)
             r = orig_w(A, B, C, opsum, which, M, N, K, lda, ldb, ldc, **kw)
-            e1.record()
+            e1.record(st)
             timer.records.setdefault(ops.gemm_kernel_label(A, C, M, N, K, True, False, kw.get('split_k', 1), True), []).append((e0, e1, 2.0 * M * N * K))
             return r
         ops.gemm_wgrad_bias = gemm_wgrad_bias

@@ -21,7 +21,28 @@ def L():
 
 
 def _s():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t the next launch goes to: the stream set by `on_stream`, else torch's current stream (the C-level
+    query: ~0.2 us instead of ~4 us through torch.cuda.Stream)."""
+    return _override_raw or _raw_stream(_cur_dev())
+
+
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_dev = torch._C._cuda_getDevice
+_override_raw = 0
+_override_stream = None
+
+
+def set_stream(stream):
+    """Route the wrappers' launches to `stream` (a torch.cuda.Stream) until set_stream(None).  Cheaper than
+    `with torch.cuda.stream(...)`; only for launches that allocate nothing (torch's allocator keeps using its own
+    current stream)."""
+    global _override_raw, _override_stream
+    _override_stream = stream
+    _override_raw = 0 if stream is None else stream.cuda_stream
+
+
+def active_stream():
+    return _override_stream if _override_stream is not None else torch.cuda.current_stream()
 
 
 def _p(t):

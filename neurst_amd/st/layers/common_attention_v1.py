@@ -34,6 +34,7 @@ def add_timing_signal_1d(x, dropout_rate=0.0, site=None, out_dtype=None, stop_gr
             if dy is None:
                 return
             if rate > 0:
+                g.before_inplace_write(dy)
                 dy = ops.dropout_bwd(dy, rate, key, out=dy)
             tape.accumulate(x, dy)
         tape.push(bwd)

@@ -6,6 +6,7 @@ There is no TF session here: `train_step(batch)` runs what `sess.run(model.list_
 (forward, backward, gradient averaging, Adam) as HIP kernel launches, `infer(features, len_feas)` runs
 what `sess.run(model_infer.list_run, feed_dict)` ran.  `list_run` keeps the reference ordering as callables.
 """
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -116,6 +117,10 @@ class TransformerTPE(Seq2SeqModel):
         self.device = torch.device(device or ('cuda:%d' % torch.cuda.current_device()))
         self.store = get_variable_store(args, name, self.device)
         self.graph = G.Graph(self.store, self.store.compute_dtype, seed=args.seed or 0)
+        if args.model.shrink_layer and 'NEURST_SIDE_WGRAD_ROWS' not in os.environ:
+            # The read-back that sizes shrink_layer's output drains the launch queue in mid-step; what follows is bound by
+            # the host's launch rate (measured: 13.9 of 14.4 ms/step), so the second stream's extra host work only costs.
+            self.graph.side_wgrad_max_rows = 0
         self.embed_table_decoder = self.get_embedding(embed_table=None, size_input=args.dim_output, size_embedding=self.size_embedding)
         if args.dirs and args.dirs.src_vocab:
             raise NotImplementedError('a separate source vocabulary (dirs.src_vocab) is outside the hot path')
@@ -137,7 +142,8 @@ class TransformerTPE(Seq2SeqModel):
         handle_gradients(self.args)
         if self.args.use_horovod:
             raise NotImplementedError('use_horovod: data parallelism is one process per GPU over RCCL (torch.distributed)')
-        self.bucketer = GradBucketer(self.store, bucket_bytes=int(self.args.grad_bucket_mb or 32) << 20)
+        self.bucketer = GradBucketer(self.store, bucket_bytes=int(self.args.grad_bucket_mb or 32) << 20,
+                                     producer_streams=lambda: (self.graph.wgrad_stream,))
         self.graph.on_param_grad = self.bucketer.param_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
         self._make_modules()
@@ -305,6 +311,7 @@ class TransformerTPE(Seq2SeqModel):
             out4 = ops.loss_combine(xent, loss_ctc, mse_partial, mse_numel, B, xent.shape[1], w_ast, w_ctc, w_kd, self.device)
             self.last.update(encoded=encoded, len_encoded=len_encoded, loss_ctc_vec=loss_ctc, xent=xent)
             tape.backward()           # `optimizer.compute_gradients(loss)` (:472)
+            g.join_side_streams()
             g.tape = None
         if self.frozen:               # frozen_scope filter (:171-183)
             for p in self.store.vars.values():

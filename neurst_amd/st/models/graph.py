@@ -4,6 +4,7 @@ names), and `optimizer.compute_gradients` (a reverse-mode Tape whose nodes launc
 backward HIP kernels).  No arithmetic happens here - only bookkeeping of device buffers.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -14,26 +15,31 @@ ALIGN = 64  # every parameter starts on a 256-byte boundary of the fp32 arena (1
 
 
 class Param:
-    __slots__ = ('name', 'shape', 'offset', 'size', 'kind', 'store')
+    __slots__ = ('name', 'shape', 'offset', 'size', 'kind', 'store', '_views')
 
     def __init__(self, name, shape, offset, kind, store):
         self.name, self.shape, self.offset, self.kind, self.store = name, tuple(shape), offset, kind, store
         self.size = int(np.prod(shape))
+        self._views = {}
 
-    def _view(self, arena):
-        return arena[self.offset:self.offset + self.size].view(self.shape)
+    def _view(self, which, arena):
+        # the arenas live as long as the store, so a view is made once (hundreds of these per step otherwise)
+        ent = self._views.get(which)
+        if ent is None or ent[0] is not arena:
+            ent = self._views[which] = (arena, arena[self.offset:self.offset + self.size].view(self.shape))
+        return ent[1]
 
     @property
     def master(self):      # fp32 master copy
-        return self._view(self.store.params)
+        return self._view('p', self.store.params)
 
     @property
     def w(self):           # operand in the compute dtype (bf16 shadow or the fp32 master)
-        return self._view(self.store.shadow if self.store.shadow is not None else self.store.params)
+        return self._view('w', self.store.shadow if self.store.shadow is not None else self.store.params)
 
     @property
     def grad(self):        # fp32 gradient (accumulated into; zeroed at the start of a step)
-        return self._view(self.store.grads)
+        return self._view('g', self.store.grads)
 
 
 class VariableStore:
@@ -140,6 +146,8 @@ class Tape:
 
     def accumulate(self, t, g):
         if id(t) in self.grads:
+            if _current:
+                _current[-1].before_inplace_write(self.grads[id(t)])
             ops.add_inplace(self.grads[id(t)], g)
         else:
             self.set(t, g)
@@ -164,6 +172,14 @@ class Graph:
         self.name_counts = {}
         self.dropout_enabled = True
         self.on_param_grad = None   # callback(Param) once a parameter's gradient kernels are enqueued
+        # Weight gradients of small layers (decoder-size row counts: grids that cannot fill the chip) run on a second
+        # HIP stream beside the data-gradient chain.  side_reads holds the storages such kernels may still be reading,
+        # so an in-place update of one of them on the main stream first waits for the side stream.
+        self.wgrad_stream = None
+        self.side_wgrad_max_rows = int(os.environ.get('NEURST_SIDE_WGRAD_ROWS', '4096'))
+        self.side_reads = set()
+        self.side_keep = []
+        self.side_used = False
 
     @contextlib.contextmanager
     def variable_scope(self, name):
@@ -207,6 +223,49 @@ class Graph:
     def param_grad_done(self, p):
         if self.on_param_grad is not None:
             self.on_param_grad(p)
+
+    # ---- second stream for small weight gradients -------------------------------------------------------------
+    def side_stream_for(self, rows, device):
+        """The stream a weight gradient over `rows` input rows should run on, or None for the current stream."""
+        if device.type != 'cuda' or rows > self.side_wgrad_max_rows or self.side_wgrad_max_rows <= 0:
+            return None
+        if self.wgrad_stream is None:
+            self.wgrad_stream = torch.cuda.Stream(device=device)
+        return self.wgrad_stream
+
+    def run_on_side(self, side, launch, *read_tensors):
+        """Enqueue `launch()` (kernels that allocate nothing and read `read_tensors`) on `side`, after everything the
+        current stream holds so far.  The tensors stay referenced until join_side_streams, so the caching allocator
+        cannot hand their memory to a later main-stream kernel while the side stream still reads it."""
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        ops.set_stream(side)
+        try:
+            launch()
+        finally:
+            ops.set_stream(None)
+        for t in read_tensors:
+            self.side_reads.add(t.untyped_storage().data_ptr())
+        self.side_keep.append(read_tensors)
+        self.side_used = True
+
+    def before_inplace_write(self, t):
+        """Main-stream kernels are about to update `t` in place: if a side-stream kernel may still read that storage,
+        wait for the side stream's tail (covers every reader enqueued so far)."""
+        if self.side_reads and t.untyped_storage().data_ptr() in self.side_reads:
+            ev = torch.cuda.Event()
+            ev.record(self.wgrad_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self.side_reads.clear()
+
+    def join_side_streams(self):
+        """Everything enqueued on the side stream happens-before what the current stream does next (Adam, all-reduce wait)."""
+        if self.side_used:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self.side_used = False
+        self.side_reads.clear()
+        self.side_keep.clear()
 
 
 _current = []

@@ -55,13 +55,19 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient):
             dy2 = _flat2d(dy)
             if dy2.dtype != x2.dtype:
                 raise TypeError('gradient dtype {} does not match operand dtype {}'.format(dy2.dtype, x2.dtype))
-            _wgrad(dy2, x2, w, layout, b)
+            side = g.side_stream_for(M, dy2.device)
+            if side is not None:     # small layer: weight (and bias) gradient beside the data-gradient chain
+                g.run_on_side(side, lambda: _wgrad(dy2, x2, w, layout, b), dy2, x2)
+            else:
+                _wgrad(dy2, x2, w, layout, b)
             g.param_grad_done(w)
             if b is not None:
                 g.param_grad_done(b)
             if not stop_gradient:
                 have = tape.has(inputs)
                 dx = tape.grad(inputs) if have else torch.empty_like(inputs)
+                if have:
+                    g.before_inplace_write(dx)
                 gate = inputs if id(inputs) in tape.relu_outputs else None
                 if layout == 'out_in':   # dX = dY . W
                     ops.gemm(dy2, w.w, dx, M, n_in, units, units, n_in, n_in, False, False, relu_src=gate, accumulate=have)

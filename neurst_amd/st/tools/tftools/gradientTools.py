@@ -14,8 +14,9 @@ _DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
 
 
 class GradBucketer:
-    def __init__(self, store, bucket_bytes=32 << 20, group=None, comm_stream=None):
+    def __init__(self, store, bucket_bytes=32 << 20, group=None, comm_stream=None, producer_streams=None):
         self.store = store
+        self.producer_streams = producer_streams or (lambda: ())   # other streams that may hold gradient kernels
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.use_stream = store.grads.is_cuda
@@ -67,6 +68,9 @@ class GradBucketer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            for st in self.producer_streams():
+                if st is not None:
+                    self.comm_stream.wait_stream(st)
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
