@@ -173,6 +173,9 @@ __device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __re
   }
 }
 
+// plain stores: non-temporal C stores measured 1-5 % faster per launch in isolation but 0.6 % slower over the step
+// (the consumer kernel then misses the memory-side cache)
+#define STORE_C(ptr, val) (*(ptr) = (val))
 constexpr int EPI_LD = 68;                                   // fp32 row stride of the per-wave epilogue tile
 constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;               // 4 waves x 32 rows x 68 floats
 
@@ -429,15 +432,15 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x8*>(C + off) = o;
+            STORE_C(reinterpret_cast<bf16x8*>(C + off), o);
           } else {
             f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
             if (g.accumulate) {
               o0 += *reinterpret_cast<const f32x4*>(C + off);
               o1 += *reinterpret_cast<const f32x4*>(C + off + 4);
             }
-            *reinterpret_cast<f32x4*>(C + off) = o0;
-            *reinterpret_cast<f32x4*>(C + off + 4) = o1;
+            STORE_C(reinterpret_cast<f32x4*>(C + off), o0);
+            STORE_C(reinterpret_cast<f32x4*>(C + off + 4), o1);
           }
         } else {
 #pragma unroll
@@ -452,6 +455,199 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------- persistent variant for grids of many tiles
+// The plain kernel above runs its tiles in rounds of two workgroups per CU that start together and therefore reach
+// their epilogues together: the chip alternates between MFMA-only and store-only phases (measured on 16000x2304x768:
+// 78 us, of which 17 us is the C write-out at HBM speed with idle matrix cores).  Here 2 workgroups per CU stay
+// resident and loop over tiles: a tile's stores drain while the next tile is already multiplying, and its first
+// operand tiles are requested before the last K-step of the current one.  The tile schedule is static: in every full
+// round of gridDim.x tiles each XCD's workgroups (blockIdx & 7) take a contiguous run of the grouped tile order - what
+// the hardware dispatcher + remap do for the plain kernel - and the tiles of the last partial round are dealt evenly to
+// the XCDs.  (Fetching tiles from per-XCD atomic counters instead cost 12-23 us per launch in contended atomics.)
+constexpr int PEPI_LD = 36;                                   // fp32 row stride of a 16 x 32 staging half-tile
+constexpr int PEPI_BYTES = 4 * 16 * PEPI_LD * 4;              // one per wave
+
+template <typename T, typename TC>
+__device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], const float (&bcol)[4], float* __restrict__ Cs,
+                                                 int64_t wrow0, int64_t wcol0, int lane) {
+  TC* C = reinterpret_cast<TC*>(g.C);
+  const T* rs = reinterpret_cast<const T*>(g.relu_src);
+  const int lg = lane >> 4, l15 = lane & 15;
+  const int rr = lane >> 2, cc = (lane & 3) * 8;
+  // relu-gradient gate: all eight chunks this lane needs are requested up front (one wait instead of eight)
+  typename Chunk<T>::V gate[8];
+  if (rs) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int64_t row = wrow0 + (p >> 1) * 16 + rr, col = wcol0 + (p & 1) * 32 + cc;
+      if (row < g.M && g.c_vec && col + 8 <= g.N) gate[p] = *reinterpret_cast<const typename Chunk<T>::V*>(rs + row * g.ldc + col);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+      // 16 rows x 32 columns of the wave's tile: MFMA layout -> LDS -> 8 consecutive columns per lane
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][jh * 2 + jj][r] + bcol[jh * 2 + jj];
+          if (g.relu) v = fmaxf(v, 0.f);
+          Cs[(lg * 4 + r) * PEPI_LD + jj * 16 + l15] = v;
+        }
+      // the same wave reads back what it wrote: LDS operations of one wave complete in order
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + rr * PEPI_LD + cc);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + rr * PEPI_LD + cc + 4);
+      const int64_t row = wrow0 + i * 16 + rr, col = wcol0 + jh * 32 + cc;
+      if (row >= g.M || col >= g.N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      const int64_t off = row * g.ldc + col;
+      if (g.c_vec && col + 8 <= g.N) {
+        if (rs) {
+          const typename Chunk<T>::V m = gate[i * 2 + jh];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = to_f32<T>(m[e]) > 0.f ? v[e] : 0.f;
+        }
+        if constexpr (sizeof(TC) == 2) {
+          if (g.accumulate) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(C + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          STORE_C(reinterpret_cast<bf16x8*>(C + off), o);
+        } else {
+          f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          if (g.accumulate) {
+            o0 += *reinterpret_cast<const f32x4*>(C + off);
+            o1 += *reinterpret_cast<const f32x4*>(C + off + 4);
+          }
+          STORE_C(reinterpret_cast<f32x4*>(C + off), o0);
+          STORE_C(reinterpret_cast<f32x4*>(C + off + 4), o1);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (col + e >= g.N) continue;
+          float x = v[e];
+          if (rs) x = to_f32<T>(rs[off + e]) > 0.f ? x : 0.f;
+          if (g.accumulate) x += to_f32<TC>(C[off + e]);
+          C[off + e] = from_f32<TC>(x);
+        }
+      }
+    }
+}
+
+// bf16 operands, direct-to-LDS staging, whole K-tiles only (K % BK == 0, K / BK >= 3), split_k == 1
+template <typename TC, bool TA, bool TB_KCONTIG>
+__global__ void __launch_bounds__(NT) gemm_persist_kernel(GemmArgs g) {
+  typedef bf16_t T;
+  constexpr int BK = (!TA && !TB_KCONTIG) ? 32 : GemmCfg<T>::BK;
+  typedef Stager<T, TA, BK> SA;
+  typedef Stager<T, !TB_KCONTIG, BK> SB;
+  constexpr int STAGE_BYTES = 2 * (SA::TILE + SB::TILE) * (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + PEPI_BYTES];
+  T* const lds = reinterpret_cast<T*>(smem);
+  auto As = [&](int b) -> T* { return lds + b * SA::TILE; };
+  auto Bs = [&](int b) -> T* { return lds + 2 * SA::TILE + b * SB::TILE; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* const Cs = reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * 16 * PEPI_LD;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int G = gridDim.x, per_xcd = G >> 3;                 // G is a multiple of 8
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
+  const int rq = rem >> 3, rr8 = rem & 7;                    // the last round's tiles: rq (+1 for the first rr8) per XCD
+  const int rem_beg = full_rounds * G + (xcd < rr8 ? xcd * (rq + 1) : rr8 * (rq + 1) + (xcd - rr8) * rq);
+  const int rem_cnt = xcd < rr8 ? rq + 1 : rq;
+  // tile of round r for this workgroup, or -1 when it has none left
+  auto tile_at = [&](int r) -> int {
+    if (r < full_rounds) return r * G + xcd * per_xcd + loc;
+    if (r == full_rounds && loc < rem_cnt) return rem_beg + loc;
+    return -1;
+  };
+  const int nfull = (int)(g.K / BK);
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+  constexpr int GM = 8;   // grouped order, as in gemm_kernel
+  const int per_group = GM * g.tiles_n;
+  auto coords = [&](int t, int64_t& m0, int64_t& n0) {
+    const int group = t / per_group, first_m = group * GM;
+    const int gsz = g.tiles_m - first_m < GM ? g.tiles_m - first_m : GM;
+    m0 = (int64_t)(first_m + (t % per_group) % gsz) * BM;
+    n0 = (int64_t)((t % per_group) / gsz) * BN;
+  };
+
+  int round = 0;
+  int tile = tile_at(0);
+  int64_t m0 = 0, n0 = 0;
+  int cur = 0;
+  if (tile >= 0) {
+    coords(tile, m0, n0);
+    issue_glds<T, TA, BK>(A, g.lda, m0, 0, g.M, As(0), tid);
+    issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, 0, g.N, Bs(0), tid);
+  }
+  while (tile >= 0) {
+    const int next = tile_at(round + 1);
+    f32x4 acc[4][4], sacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int64_t nm0 = 0, nn0 = 0;
+    // bias of the columns this lane holds in the MFMA layout: requested here, landed by the first barrier (requested
+    // inside the K loop they become loop-carried pending loads and the compiler waits for them in every iteration)
+    float bcol[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 16 + (lane & 15);
+        bcol[j] = col < g.N ? g.bias[col] : 0.f;
+      }
+    }
+    for (int it = 0; it < nfull; ++it) {
+      __syncthreads();   // K-tile `it` has landed (vmcnt(0) precedes the barrier) and buf[cur^1] is no longer read
+      if (it + 1 < nfull) {
+        const int64_t kn = (int64_t)(it + 1) * BK;
+        issue_glds<T, TA, BK>(A, g.lda, m0, kn, g.M, As(cur ^ 1), tid);
+        issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kn, g.N, Bs(cur ^ 1), tid);
+      } else if (next >= 0) {   // first K-tile of the next output tile: in flight during this tile's last K-step and epilogue
+        coords(next, nm0, nn0);
+        issue_glds<T, TA, BK>(A, g.lda, nm0, 0, g.M, As(cur ^ 1), tid);
+        issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, nn0, 0, g.N, Bs(cur ^ 1), tid);
+      }
+      mma_tile<T, SA, SB, 0>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
+      cur ^= 1;
+    }
+    persist_epilogue<T, TC>(g, acc, bcol, Cs, m0 + wm * 64, n0 + wn * 64, lane);
+    tile = next; m0 = nm0; n0 = nn0;
+    ++round;
+  }
+}
+
+static int persist_min_tiles() {
+  static const int v = [] { const char* e = getenv("NEURST_GEMM_PERSIST_MIN_TILES"); return e ? atoi(e) : 1024; }();
+  return v;
+}
+
+// true if the launch was taken by the persistent kernel.  Measured on the LUT shapes (M = 16000, K = 768): NT 1.5-3 %
+// faster than the plain kernel from 1024 tiles up (no gain below: a single round has nothing to overlap); NN (K-tiles of
+// 32, twice the barriers per tile) 8 % slower, so only NT takes it.  NEURST_GEMM_PERSIST_MIN_TILES moves the threshold.
+template <typename TC>
+static bool launch_gemm_persist(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
+  if (trans_a || !trans_b) return false;
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
+  if (g.split_k != 1 || g.K % 64 != 0 || g.K / 64 < 3 || tiles < persist_min_tiles()) return false;
+  const int grid = 512;   // 2 resident workgroups on each of the 256 CUs; the kernel needs a multiple of 8
+  gemm_persist_kernel<TC, false, true><<<grid, NT, 0, s>>>(g);
+  return true;
 }
 
 // grids of at most one workgroup per CU cannot hide load latency behind other workgroups: deep pipeline instead
@@ -470,6 +666,7 @@ template <typename T, typename TC, bool FAST>
 static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
   if constexpr (FAST) {
     if (small_grid(g)) return launch_gemm_ns<T, TC, true, 4>(g, trans_a, trans_b, s);
+    if (launch_gemm_persist<TC>(g, trans_a, trans_b, s)) return 0;
   }
   return launch_gemm_ns<T, TC, FAST, 2>(g, trans_a, trans_b, s);
 }

@@ -10,7 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'neurst_hip.h')
-LIB_PATH = os.path.join(_HERE, 'libneurst_hip.so')
+LIB_PATH = os.environ.get('NEURST_HIP_LIB') or os.path.join(_HERE, 'libneurst_hip.so')   # override: kernel A/B experiments (tools/exp)
 
 F32, BF16 = 0, 1
 MASK_NONE, MASK_KEYPAD, MASK_CAUSAL = 0, 1, 2

@@ -3,6 +3,7 @@ only as device buffers (`data_ptr()`) and for the current HIP stream; no torch o
 arithmetic on the hot path.  Every wrapper raises if the kernel library reports an error.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -159,6 +160,9 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias=None, relu=Fals
     return C
 
 
+PERSIST_MIN_TILES = int(os.environ.get('NEURST_GEMM_PERSIST_MIN_TILES', '1024'))   # csrc/gemm.hip: persist_min_tiles()
+
+
 def gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, split_k=1, bias_grad=False):
     """Which instantiation of gemm_kernel (csrc/gemm.hip) a call runs - mirrors the host dispatch there; used by bench.py
     to group its per-launch timings the way rocprofv3 groups kernels."""
@@ -168,6 +172,8 @@ def gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, split_k=1, bias_grad=Fals
     fast = ab == 'bf16' and K % 8 == 0 and (not trans_a or M % 8 == 0) and (trans_b or N % 8 == 0)
     tiles = -(-M // 128) * -(-N // 128) * max(split_k, 1)
     ns = 4 if (fast and tiles <= 256 and K >= 256) else 2
+    if fast and lay == 'NT' and ns == 2 and split_k <= 1 and not bias_grad and K % 64 == 0 and K >= 192 and tiles >= PERSIST_MIN_TILES:
+        return 'gemm_persist_kernel<%s,%s,NT>' % (ab, c)
     return 'gemm_kernel<%s,%s,%s,%s,stages=%d%s>' % (ab, c, lay, 'direct-to-LDS' if fast else 'register-staged', ns, ',+bias-grad' if bias_grad else '')
 
 

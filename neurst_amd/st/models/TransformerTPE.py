@@ -117,10 +117,11 @@ class TransformerTPE(Seq2SeqModel):
         self.device = torch.device(device or ('cuda:%d' % torch.cuda.current_device()))
         self.store = get_variable_store(args, name, self.device)
         self.graph = G.Graph(self.store, self.store.compute_dtype, seed=args.seed or 0)
-        if args.model.shrink_layer and 'NEURST_SIDE_WGRAD_ROWS' not in os.environ:
-            # The read-back that sizes shrink_layer's output drains the launch queue in mid-step; what follows is bound by
-            # the host's launch rate (measured: 13.9 of 14.4 ms/step), so the second stream's extra host work only costs.
-            self.graph.side_wgrad_max_rows = 0
+        if args.model.shrink_layer and G.side_wgrad_rows_from_env() is None:
+            # The read-back that sizes shrink_layer's output drains the launch queue in mid-step; the small layers that
+            # follow are bound by the host's launch rate (measured: 13.9 of 14.4 ms/step), where the second stream's
+            # extra host work only costs.  The large layers of the acoustic encoder's backward still gain from it.
+            self.graph.side_wgrad_rows = (8192, 1 << 40)
         self.embed_table_decoder = self.get_embedding(embed_table=None, size_input=args.dim_output, size_embedding=self.size_embedding)
         if args.dirs and args.dirs.src_vocab:
             raise NotImplementedError('a separate source vocabulary (dirs.src_vocab) is outside the hot path')
@@ -222,7 +223,7 @@ class TransformerTPE(Seq2SeqModel):
         # and in the backward of the CTC head, so it runs on its own HIP stream beside the semantic encoder and
         # the decoder - unless shrink_layer needs the arg-max right away.
         side = None
-        if want_ctc_grad and not a.model.shrink_layer and logits_am.is_cuda:
+        if want_ctc_grad and not a.model.shrink_layer and logits_am.is_cuda and g.side_streams:
             if self._ctc_stream is None:
                 self._ctc_stream = torch.cuda.Stream(device=self.device)
             side = self._ctc_stream
@@ -239,7 +240,7 @@ class TransformerTPE(Seq2SeqModel):
             else:
                 # shrink_layer needs the arg-max now: only the recursion and the gradient correction leave the main stream
                 rs = None
-                if logits_am.is_cuda:
+                if logits_am.is_cuda and g.side_streams:
                     if self._ctc_stream is None:
                         self._ctc_stream = torch.cuda.Stream(device=self.device)
                     rs = self._ctc_stream

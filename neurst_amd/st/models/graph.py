@@ -158,6 +158,14 @@ class Tape:
         self.nodes.clear()
 
 
+def side_wgrad_rows_from_env():
+    v = os.environ.get('NEURST_SIDE_WGRAD_ROWS')
+    if not v:
+        return None
+    lo, _, hi = v.partition(':')
+    return (int(lo), int(hi)) if hi else (1, int(lo))
+
+
 class Graph:
     """One model's execution context (TF: default graph + variable scope + train/eval flag)."""
 
@@ -172,11 +180,14 @@ class Graph:
         self.name_counts = {}
         self.dropout_enabled = True
         self.on_param_grad = None   # callback(Param) once a parameter's gradient kernels are enqueued
-        # Weight gradients of small layers (decoder-size row counts: grids that cannot fill the chip) run on a second
-        # HIP stream beside the data-gradient chain.  side_reads holds the storages such kernels may still be reading,
-        # so an in-place update of one of them on the main stream first waits for the side stream.
+        # Weight gradients run on a second HIP stream beside the data-gradient chain: small layers cannot fill the chip on
+        # their own, and for large ones each kernel's ramp-up and drain (~12 us per launch, measured) is covered by the
+        # other stream's steady state.  side_wgrad_rows = (min, max) input rows of the layers that take part
+        # (NEURST_SIDE_WGRAD_ROWS=min:max overrides; 0:0 turns it off).  side_reads holds the storages such kernels may
+        # still be reading, so an in-place update of one of them on the main stream first waits for the side stream.
+        self.side_streams = os.environ.get('NEURST_SIDE_STREAMS', '1') != '0'   # False: everything on the current stream
         self.wgrad_stream = None
-        self.side_wgrad_max_rows = int(os.environ.get('NEURST_SIDE_WGRAD_ROWS', '4096'))
+        self.side_wgrad_rows = side_wgrad_rows_from_env() or (1, 1 << 40)
         self.side_reads = set()
         self.side_keep = []
         self.side_used = False
@@ -227,7 +238,8 @@ class Graph:
     # ---- second stream for small weight gradients -------------------------------------------------------------
     def side_stream_for(self, rows, device):
         """The stream a weight gradient over `rows` input rows should run on, or None for the current stream."""
-        if device.type != 'cuda' or rows > self.side_wgrad_max_rows or self.side_wgrad_max_rows <= 0:
+        lo, hi = self.side_wgrad_rows
+        if not self.side_streams or device.type != 'cuda' or rows < lo or rows > hi:
             return None
         if self.wgrad_stream is None:
             self.wgrad_stream = torch.cuda.Stream(device=device)

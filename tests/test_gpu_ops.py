@@ -79,6 +79,34 @@ def test_gemm_deep_pipeline_small_grids(ta, tb, M, N, K):
         assert relerr(host(C), ref) < 1e-5
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize('M,N,K,cdt', [(4100, 4000, 192, 'bf16'), (5000, 3592, 256, 'f32'), (16000, 1536, 768, 'bf16')])
+def test_gemm_persistent_many_tiles(ta, tb, M, N, K, cdt):
+    """aligned bf16 problems of >= 1024 tiles take the persistent kernel (atomic tile counters per XCD, next tile's operands
+    requested during the current epilogue): ragged edges, bias + relu, accumulate and the relu-gradient gate; repeated
+    launches exercise the counter ring."""
+    rng = np.random.default_rng(M + K)
+    A = bf16_round(rng.standard_normal((K, M) if ta else (M, K)))
+    B = bf16_round(rng.standard_normal((N, K) if tb else (K, N)))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float32) @ (B.T if tb else B).astype(np.float32)
+    tc = torch.bfloat16 if cdt == 'bf16' else torch.float32
+    tol = 1e-2 if cdt == 'bf16' else 1e-5
+    dA, dB = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    for rep in range(3):
+        C = torch.empty((M, N), dtype=tc, device=DEV)
+        ops.gemm(dA, dB, C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias))
+        assert relerr(host(C), ref + bias) < tol, rep
+    C2 = torch.full((M, N), 0.5, dtype=tc, device=DEV)
+    ops.gemm(dA, dB, C2, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias), relu=True, accumulate=True)
+    assert relerr(host(C2), np.maximum(ref + bias, 0) + 0.5) < tol
+    if cdt == 'bf16':
+        gate = bf16_round(rng.standard_normal((M, N)))
+        C3 = torch.empty((M, N), dtype=tc, device=DEV)
+        ops.gemm(dA, dB, C3, M, N, K, A.shape[1], B.shape[1], N, ta, tb, relu_src=dev(gate, torch.bfloat16))
+        assert relerr(host(C3), ref * (gate > 0)) < tol
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_gemm_splitk_and_relu_gate(dtype):
     rng = np.random.default_rng(5)

@@ -56,7 +56,13 @@ def bench_gemm():
         fn = lambda: ops.gemm(A, B, C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, accumulate=sk > 1 or split is None, split_k=sk)
         med, mn = timeit(fn)
         fl = 2.0 * M * N * K
-        print('%-16s M=%5d N=%5d K=%5d split=%2d  med %8.1f us  min %8.1f us  %7.1f TF/s' % (name, M, N, K, sk, med, mn, fl / med / 1e6))
+        line = '%-16s M=%5d N=%5d K=%5d split=%2d  med %8.1f us  min %8.1f us  %7.1f TF/s' % (name, M, N, K, sk, med, mn, fl / med / 1e6)
+        if os.environ.get('YARDSTICK'):   # the vendor library on the same shape: a yardstick for this tool only, never on the product path
+            At, Bt = (A.t() if ta else A), (B.t() if tb else B)
+            Cl = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            lm, _ = timeit(lambda: torch.mm(At, Bt, out=Cl))
+            line += '   | library %8.1f us %7.1f TF/s' % (lm, fl / lm / 1e6)
+        print(line)
 
 
 def bench_attn():

@@ -17,6 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def gemm_label(name):
     """mangled / half-demangled gemm_kernel<T, TC, TA, TB_KCONTIG, FAST, SUMOP, NS> -> the label bench.py uses"""
+    mp = re.match(r'_Z19gemm_persist_kernelI(DF16b|f)Lb([01])ELb([01])EEv8GemmArgs', name)
+    if mp:
+        lay = {('0', '1'): 'NT', ('0', '0'): 'NN', ('1', '0'): 'TN'}[mp.groups()[1:]]
+        return 'gemm_persist_kernel<bf16,%s,%s>' % ('bf16' if mp.group(1) == 'DF16b' else 'f32', lay)
     m = re.match(r'_Z11gemm_kernelI(DF16b|f)(DF16b|f)Lb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)EEv8GemmArgs', name)
     if m:
         t, tc, ta, tbk, fast, sumop, ns = m.groups()
