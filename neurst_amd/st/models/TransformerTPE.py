@@ -99,8 +99,9 @@ def get_variable_store(args, name, device):
     key = (id(args), name)
     if key not in _STORES:
         dtype = ops.BF16 if str(args.compute_dtype).lower() in ('bf16', 'bfloat16') else ops.F32
-        _STORES[key] = G.VariableStore(variable_specs(args, name), device, dtype, seed=1 if args.init_seed is None else args.init_seed)
-    return _STORES[key]
+        # the entry keeps `args` alive: a collected args object could hand its id() to a new configuration
+        _STORES[key] = (args, G.VariableStore(variable_specs(args, name), device, dtype, seed=1 if args.init_seed is None else args.init_seed))
+    return _STORES[key][1]
 
 
 class TransformerTPE(Seq2SeqModel):
@@ -143,7 +144,7 @@ class TransformerTPE(Seq2SeqModel):
         handle_gradients(self.args)
         if self.args.use_horovod:
             raise NotImplementedError('use_horovod: data parallelism is one process per GPU over RCCL (torch.distributed)')
-        self.bucketer = GradBucketer(self.store, bucket_bytes=int(self.args.grad_bucket_mb or 32) << 20,
+        self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 32) * (1 << 20)) // 256 * 256, 256),
                                      producer_streams=lambda: (self.graph.wgrad_stream,))
         self.graph.on_param_grad = self.bucketer.param_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
@@ -320,23 +321,39 @@ class TransformerTPE(Seq2SeqModel):
                     p.grad.zero_()
         return out4
 
+    def _step(self, batch):
+        """forward + backward + gradient mean + Adam.  NEURST_OVERLAP_ADAM=1: the Adam update of a gradient bucket is
+        enqueued on a side stream as soon as backward has finished with the bucket (GradBucketer) instead of one launch
+        over the whole arena at the end.  Off by default: on one MI355X it measured 1.7 % SLOWER (LUT 17.05 vs 16.76
+        ms/step) - Adam streams 30 B per parameter and takes HBM bandwidth and memory-side cache from the GEMMs it
+        overlaps."""
+        overlap = (not self.frozen) and self.graph.side_streams and self.device.type == 'cuda' and \
+            os.environ.get('NEURST_OVERLAP_ADAM', '0') == '1'
+        if overlap:
+            lr, self.bucketer.apply_fn = self.optimizer_update_fn(self.store, 1.0 / self.bucketer.world)
+        try:
+            out4 = self.forward_backward(batch)
+            scale = average_gradients(self.bucketer)
+        finally:
+            self.bucketer.apply_fn = None
+        if overlap:
+            self.finish_update(self.store)
+            self.last['lr'] = lr
+        else:
+            self.last['lr'] = self.apply_gradients(self.store, scale)
+        return out4
+
     def train_step(self, batch):
         """One `sess.run([model.list_run, loss_ast, loss_am, loss_bert])` (run_lut.py:365-368):
         returns (loss, shape_batch, loss_ast, loss_ctc, loss_bert) as Python floats (one 16-byte read back)."""
-        out4 = self.forward_backward(batch)
-        scale = average_gradients(self.bucketer)
-        self.last['lr'] = self.apply_gradients(self.store, scale)
-        vals = out4.cpu().numpy()
+        vals = self._step(batch).cpu().numpy()
         self.last['loss'] = float(vals[0])
         self.loss_ast, self.loss_am, self.loss_bert = float(vals[1]), float(vals[2]), float(vals[3])
         return self.last['loss'], self.last['shape_batch'], self.loss_ast, self.loss_am, self.loss_bert
 
     def train_step_async(self, batch):
         """Same as train_step without the read back (throughput runs): returns the [4] device tensor."""
-        out4 = self.forward_backward(batch)
-        scale = average_gradients(self.bucketer)
-        self.last['lr'] = self.apply_gradients(self.store, scale)
-        return out4
+        return self._step(batch)
 
     # ------------------------------------------------------------------ inference (:486-513, :314-325)
     def infer(self, features, len_feas):

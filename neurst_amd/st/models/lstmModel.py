@@ -41,13 +41,26 @@ class LSTM_Model(object):
             raise NotImplementedError('only optimizer: adam is on the hot path')
         return self
 
-    def apply_gradients(self, store, grad_scale):
-        """TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v update; theta -= lr_t*m/(sqrt(v)+eps); global_step += 1."""
+    def optimizer_update_fn(self, store, grad_scale):
+        """-> (lr, fn): fn(start, end) enqueues this step's Adam update of arena[start:end] on the current stream
+        (used to update gradient buckets while backward is still running); finish_update() closes the step."""
         lr = self.lr_at(self.global_step.value)
-        store.adam_t += 1
-        t = store.adam_t
+        t = store.adam_t + 1
         b1, b2 = self.ADAM_BETA1, self.ADAM_BETA2
         lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-        _ops.adam_step(store.params, store.grads, store.m, store.v, store.shadow, lr_t, b1, b2, self.ADAM_EPS, grad_scale)
+
+        def fn(s, e):
+            _ops.adam_step(store.params[s:e], store.grads[s:e], store.m[s:e], store.v[s:e],
+                           None if store.shadow is None else store.shadow[s:e], lr_t, b1, b2, self.ADAM_EPS, grad_scale)
+        return lr, fn
+
+    def finish_update(self, store):
+        store.adam_t += 1
         self.global_step.value += 1
+
+    def apply_gradients(self, store, grad_scale):
+        """TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v update; theta -= lr_t*m/(sqrt(v)+eps); global_step += 1."""
+        lr, fn = self.optimizer_update_fn(store, grad_scale)
+        fn(0, store.total)
+        self.finish_update(store)
         return lr

@@ -14,6 +14,15 @@ _DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
 
 
 class GradBucketer:
+    """Completion tracking of the gradient arena in contiguous buckets.
+
+    world > 1: a bucket is all-reduced (sum) on the communication stream as soon as backward has enqueued every kernel
+    that writes it.  If `apply_fn(start, end)` is set (it enqueues the optimizer update of arena[start:end] on the
+    current stream), a bucket is also UPDATED during backward, on that same side stream, behind its all-reduce: Adam is
+    HBM-bound and hides under the matrix-core work of the remaining backward.  The update of a bucket is enqueued one
+    bucket late - when the NEXT bucket completes - because the data-gradient GEMM of the layer that completed it still
+    reads the weights and is enqueued right after the completion call."""
+
     def __init__(self, store, bucket_bytes=32 << 20, group=None, comm_stream=None, producer_streams=None):
         self.store = store
         self.producer_streams = producer_streams or (lambda: ())   # other streams that may hold gradient kernels
@@ -21,6 +30,7 @@ class GradBucketer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.use_stream = store.grads.is_cuda
         self.comm_stream = comm_stream or (torch.cuda.Stream() if (self.use_stream and self.world > 1) else None)
+        self.apply_fn = None
         elems = max(bucket_bytes // 4, 1)
         # buckets follow arena order; a parameter belongs to the bucket of its first element
         self.bounds = []
@@ -42,53 +52,102 @@ class GradBucketer:
     def reset(self):
         self.pending = list(self.bucket_params)
         self.done_params = set()
-        self.handles = []
+        self.handles = [None] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
+        self.applied = [False] * len(self.bounds)
+        self.waiting = None          # completed bucket whose update is still held back (see class docstring)
+
+    def _side_stream(self):
+        if self.use_stream and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream()
+        return self.comm_stream
 
     def param_done(self, p):
         """Called by backward once every kernel writing p.grad has been enqueued."""
-        if self.world == 1 or p.name in self.done_params:
+        if self.world == 1 and self.apply_fn is None:
+            return
+        first, last = self.param_bucket[p.name]
+        if p.name in self.done_params:
+            # a variable used by two layers: its first user already reported it.  Harmless while the bucket is untouched
+            # (kernels run in stream order), an error once the bucket has been reduced or updated without this gradient.
+            if any(self.applied[b] or (self.launched[b] and self.world > 1) for b in range(first, last + 1)):
+                raise RuntimeError('gradient of shared variable {} produced after its bucket was reduced/updated'.format(p.name))
             return
         self.done_params.add(p.name)
-        first, last = self.param_bucket[p.name]
         for b in range(first, last + 1):
             self.pending[b] -= 1
             if self.pending[b] == 0:
-                self._launch(b)
+                self._complete(b)
+
+    def _complete(self, b):
+        if self.world > 1:
+            self._launch(b)
+        if self.apply_fn is not None:
+            if self.waiting is not None:
+                self._apply(self.waiting)
+            self.waiting = b
+
+    def _wait_for_producers(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        stream.wait_event(ev)
+        for st in self.producer_streams():
+            if st is not None:
+                stream.wait_stream(st)
 
     def _launch(self, b):
         if self.launched[b]:
             return
         self.launched[b] = True
         if _DEBUG:
-            print('[bucketer r%d] launch bucket %d of %d (%d handles so far)' % (dist.get_rank(), b, len(self.bounds), len(self.handles)), flush=True)
+            print('[bucketer r%d] launch bucket %d of %d' % (dist.get_rank(), b, len(self.bounds)), flush=True)
         s, e = self.bounds[b]
         view = self.store.grads[s:e]
         if self.comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
-            for st in self.producer_streams():
-                if st is not None:
-                    self.comm_stream.wait_stream(st)
+            self._wait_for_producers(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.handles[b] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.handles[b] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _apply(self, b):
+        """Optimizer update of bucket b behind everything enqueued so far (current stream, producer streams, its all-reduce)."""
+        if self.applied[b]:
+            return
+        self.applied[b] = True
+        s, e = self.bounds[b]
+        side = self._side_stream()
+        if side is None:                      # host tensors (gloo tests): everything is synchronous
+            if self.handles[b] is not None:
+                self.handles[b].wait()
+            self.apply_fn(s, e)
+            return
+        self._wait_for_producers(side)
+        with torch.cuda.stream(side):
+            if self.handles[b] is not None:
+                self.handles[b].wait()        # NCCL work: makes `side` wait, not the host
+            self.apply_fn(s, e)
 
     def finish(self):
-        """Launch whatever is left (parameters without gradient this step) and wait for all buckets."""
-        if self.world == 1:
-            return 1.0
-        for b in range(len(self.bounds)):
-            self._launch(b)
-        for i, h in enumerate(self.handles):
-            h.wait()
-            if _DEBUG:
-                print('[bucketer r%d] handle %d done' % (dist.get_rank(), i), flush=True)
+        """Launch whatever is left (parameters without gradient this step), wait for all buckets; with apply_fn set also
+        update every bucket not updated yet.  Returns the 1/world of the mean (already used by apply_fn if that is set)."""
+        scale = 1.0 / self.world
+        if self.world == 1 and self.apply_fn is None:
+            return scale
+        if self.world > 1:
+            for b in range(len(self.bounds)):
+                self._launch(b)
+        if self.apply_fn is not None:
+            for b in reversed(range(len(self.bounds))):
+                self._apply(b)
+        else:
+            for i, h in enumerate(self.handles):
+                if h is not None:
+                    h.wait()
+                    if _DEBUG:
+                        print('[bucketer r%d] handle %d done' % (dist.get_rank(), i), flush=True)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        scale = 1.0 / self.world
         self.reset()
         return scale
 

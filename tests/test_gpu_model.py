@@ -138,9 +138,16 @@ def test_fp32_greedy_ids_bit_exact_and_ctc_preds():
     assert np.array_equal(model.last['len_decoded'], rlen)
 
 
-def test_train_steps_follow_oracle_adam_and_lr():
+@pytest.mark.parametrize('bucket_mb,overlap', [(None, '1'), (0.004, '1'), (0.004, '0')])
+def test_train_steps_follow_oracle_adam_and_lr(bucket_mb, overlap, monkeypatch):
+    """bucket_mb 0.004: ~40 gradient buckets of 1024 elements, each updated by its own Adam launch on the side stream
+    while backward is still running (overlap '1') or all at once after it ('0')."""
+    monkeypatch.setenv('NEURST_OVERLAP_ADAM', overlap)
     args = ge.tiny_args(compute_dtype='fp32')
+    args.grad_bucket_mb = bucket_mb
     model = make_model(args, step=0)
+    if bucket_mb:
+        assert len(model.bucketer.bounds) > 8
     P = {k: v.astype(np.float64) for k, v in perturb(model).items()}
     M = {k: np.zeros_like(v) for k, v in P.items()}
     V = {k: np.zeros_like(v) for k, v in P.items()}

@@ -133,6 +133,34 @@ st.grads = torch.ones(st.total) * (rank + 1)
 for n in ['p0'] + order:
     b.param_done(st.vars[n])
 assert average_gradients(b) == 0.5 and torch.equal(st.grads, torch.ones(st.total) * 3)
+# third step: buckets are also UPDATED while "backward" runs - each exactly once, only after its all-reduce, and one
+# bucket late (the layer that completes a bucket still reads its weights right after reporting)
+st.grads = torch.ones(st.total) * (rank + 1)
+seen = []
+def apply_fn(s, e):
+    assert torch.equal(st.grads[s:e], torch.ones(e - s) * 3), 'update before the all-reduce'
+    seen.append((s, e))
+b.apply_fn = apply_fn
+during = []
+for n in order:
+    b.param_done(st.vars[n])
+    during.append(len(seen))
+completed = sum(1 for x in b.pending if x == 0)
+assert during[-1] == completed - 1 and during[-1] >= 1, (during, completed)     # the newest completed bucket is held back
+assert average_gradients(b) == 0.5
+assert sorted(seen) == list(b.bounds), seen                                     # every bucket once, p0's included
+b.apply_fn = None
+# a variable reported twice is fine while its bucket is untouched, an error afterwards
+b.apply_fn = lambda s, e: None
+b.param_done(st.vars['p5']); b.param_done(st.vars['p4']); b.param_done(st.vars['p4'])
+for n in ['p3', 'p1', 'p2']:
+    b.param_done(st.vars[n])
+try:
+    b.param_done(st.vars['p4'])
+    raise SystemExit('late gradient of a shared variable was accepted')
+except RuntimeError:
+    pass
+average_gradients(b)
 dist.destroy_process_group()
 print('rank', rank, 'ok')
 '''

@@ -50,7 +50,7 @@ def main(tag):
     shutil.copy(os.path.join(src, 'stats', 's_kernel_stats.csv'), os.path.join(dst, tag + '_bench_lut_kernel_stats.csv'))
     f = counters(os.path.join(src, 'fetch', 'f_counter_collection.csv'))
     w = counters(os.path.join(src, 'write', 'w_counter_collection.csv'))
-    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing',
+    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams',
            'formula': 'bytes = 1000 * (2 * mean(FETCH_SIZE) + mean(WRITE_SIZE)); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B reads at 64 B); Infinity-Cache hits are included',
            'bytes_per_launch': {}, 'raw_kernel_names': {}}
     for k in sorted(f):
