@@ -77,6 +77,21 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Same sum through the DPP cross-lane network instead of six LDS-crossbar shuffles (~60 instead of ~600 cycles of
+// latency per reduction - what a one-row-per-wave kernel waits for twice per row).  Needs all 64 lanes active; the
+// result is wave-uniform.  Steps: quad swaps, half-row mirror, row mirror (every lane of a 16-lane row now holds the
+// row's sum), lane 15 -> next row (rows 1, 3), lane 31 -> rows 2, 3; lane 63 then holds the total.
+#define NEURST_DPP_F32(x, ctrl, rows) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rows), 0xF, false))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += NEURST_DPP_F32(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  v += NEURST_DPP_F32(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  v += NEURST_DPP_F32(v, 0x141, 0xF);   // row_half_mirror
+  v += NEURST_DPP_F32(v, 0x140, 0xF);   // row_mirror
+  v += NEURST_DPP_F32(v, 0x142, 0xA);   // row_bcast:15 into rows 1 and 3 (0 elsewhere)
+  v += NEURST_DPP_F32(v, 0x143, 0xC);   // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 // block-wide sum for blockDim.x multiple of 64 (<= 1024); red must hold 16 floats
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

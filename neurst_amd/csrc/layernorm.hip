@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __
     }
     float mu[R], rs[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) mu[r] = wave_sum(s[r]) * invC;
+    for (int r = 0; r < R; ++r) mu[r] = wave_sum_dpp(s[r]) * invC;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float q = 0.f;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __
       s[r] = q;
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) rs[r] = 1.0f / sqrtf(wave_sum(s[r]) * invC + LN_EPS);
+    for (int r = 0; r < R; ++r) rs[r] = 1.0f / sqrtf(wave_sum_dpp(s[r]) * invC + LN_EPS);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = row0 + r;
@@ -181,14 +181,15 @@ __global__ void ln_fwd_generic(const T* __restrict__ x, T* __restrict__ yz, cons
 
 // ------------------------------------------------------------------ backward (vector path)
 template <typename T, int VEC, int NCH>
-__global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ gamma,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dz,
                                                    T* __restrict__ dy, float* __restrict__ partial, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int64_t rows, int C, uint32_t thr,
                                                    float scale, uint32_t key, uint32_t inner0, int idx32,
                                                    const int32_t* __restrict__ lens, int64_t Tn) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sm = reinterpret_cast<float*>(smem_raw);  // [2][4][C]
+  float* sm = reinterpret_cast<float*>(smem_raw);  // [2][nw][C]
+  const int nw = blockDim.x >> 6;           // 4 or 8 waves: one row per wave in flight, so more waves = more rows in flight
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunks = C / VEC;
   const float invC = 1.f / (float)C;
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, co
     for (int j = 0; j < VEC; ++j) { dgam[c][j] = 0.f; dbet[c][j] = 0.f; }
     load_param<VEC>(gamma, ch, ch < nchunks, pvec, gv[c]);
   }
-  for (int64_t row = blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * nw + w; row < rows; row += (int64_t)gridDim.x * nw) {
     bool keep_row = true;
     if (lens) keep_row = (row % Tn) < lens[row / Tn];
     const float mu = mean[row], rs = rstd[row];
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, co
         for (int j = 0; j < VEC; ++j) { g[c][j] = 0.f; xh[c][j] = 0.f; }
       }
     }
-    const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+    const float m1 = wave_sum_dpp(s1) * invC, m2 = wave_sum_dpp(s2) * invC;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       int ch = lane + 64 * c;
@@ -255,16 +256,16 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dout, co
     if (ch < nchunks) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        sm[(0 * 4 + w) * C + ch * VEC + j] = dgam[c][j];
-        sm[(1 * 4 + w) * C + ch * VEC + j] = dbet[c][j];
+        sm[(0 * nw + w) * C + ch * VEC + j] = dgam[c][j];
+        sm[(1 * nw + w) * C + ch * VEC + j] = dbet[c][j];
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
     int which = i / C, col = i % C;
-    float s = sm[(which * 4 + 0) * C + col] + sm[(which * 4 + 1) * C + col] + sm[(which * 4 + 2) * C + col] +
-              sm[(which * 4 + 3) * C + col];
+    float s = 0.f;
+    for (int ww = 0; ww < nw; ++ww) s += sm[(which * nw + ww) * C + col];
     if (partial) partial[((int64_t)blockIdx.x * 2 + which) * C + col] = s;
     else atomicAdd((which ? dbeta : dgamma) + col, s);   // a few hundred adds per address: cheaper than a second launch
   }
@@ -328,9 +329,14 @@ static inline int ln_nch(int64_t C, int vec) { return (int)cdiv64(C / vec, 64); 
 static inline bool ln_vec_ok(int64_t C, int vec, const void* a, const void* b, const void* c) {
   return C % vec == 0 && ln_nch(C, vec) <= 8 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0) && C % 4 == 0;
 }
+// Launch shape of ln_bwd_vec.  The tail of every workgroup adds 2 C column partials to dgamma / dbeta with atomics, so few,
+// fat workgroups win: measured on 16000 x 768 (rate 0.1): 512 x 256 threads 42.8 us, 512 x 512 35.0, 256 x 1024 33.8
+// (one workgroup of 16 waves per CU: 16 rows in flight per CU), 320 x 1024 42.6, 128 x 1024 44.1.
+static int ln_bwd_threads(int64_t rows) { return rows >= 4096 ? 1024 : 256; }
 extern "C" int64_t neurst_layernorm_bwd_blocks(int64_t rows) {
-  int64_t g = cdiv64(rows, 4);
-  return g > 512 ? 512 : (g < 1 ? 1 : g);   // measured on 16000 x 768: 256 blocks 56 us, 512 45 us, 768 45 us, 1024 54 us
+  const int64_t per = ln_bwd_threads(rows) / 64, cap = rows >= 4096 ? 256 : 512;
+  const int64_t g = cdiv64(rows, per);
+  return g > cap ? cap : (g < 1 ? 1 : g);
 }
 
 extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const float* gamma, const float* beta, void* out,
@@ -382,7 +388,8 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   float sc = keep_scale(rate);
   int grid = (int)neurst_layernorm_bwd_blocks(rows);
   hipStream_t s = as_stream(stream);
-  size_t shmem = (size_t)8 * C * sizeof(float);
+  const int nthr = ln_bwd_threads(rows);
+  size_t shmem = (size_t)2 * (nthr / 64) * C * sizeof(float);
   bool vec = false;
   // column sums: workgroups add their LDS-reduced partials straight into dgamma / dbeta (measured 45 us against
   // 38 + 12 us for partial buffers plus a second reduction launch); `partial` is kept in the ABI and, when given,
@@ -391,7 +398,8 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   const uint32_t inner0 = fmix32(key);
   const int idx32 = (double)rows * (double)C < 4294967296.0;
 #define BWD_VEC(TT, VEC, NCH)                                                                                                \
-  ln_bwd_vec<TT, VEC, NCH><<<grid, 256, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, use_partial ? partial : nullptr, \
+  if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec<TT, VEC, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+  ln_bwd_vec<TT, VEC, NCH><<<grid, nthr, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, use_partial ? partial : nullptr, \
                                                     dgamma, dbeta, rows, (int)C, thr, sc, key, inner0, idx32, lens, T)
 #define BWD_DISPATCH(TT, VEC)                                         \
   switch (ln_nch(C, VEC)) {                                           \
@@ -402,10 +410,10 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
     default: BWD_VEC(TT, VEC, 8); break;                              \
   }
   if (dtype == NEURST_BF16) {
-    if (ln_vec_ok(C, 8, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 64 * 1024) { vec = true; BWD_DISPATCH(bf16_t, 8) }
+    if (ln_vec_ok(C, 8, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 150 * 1024) { vec = true; BWD_DISPATCH(bf16_t, 8) }
     else ln_bwd_generic<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)z, gamma, mean, rstd, (bf16_t*)dz, (bf16_t*)dy, dgamma, dbeta, rows, (int)C, thr, sc, key, lens, T);
   } else {
-    if (ln_vec_ok(C, 4, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 64 * 1024) { vec = true; BWD_DISPATCH(float, 4) }
+    if (ln_vec_ok(C, 4, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 150 * 1024) { vec = true; BWD_DISPATCH(float, 4) }
     else ln_bwd_generic<float><<<grid, 256, 0, s>>>((const float*)dout, (const float*)z, gamma, mean, rstd, (float*)dz, (float*)dy, dgamma, dbeta, rows, (int)C, thr, sc, key, lens, T);
   }
 #undef BWD_DISPATCH
