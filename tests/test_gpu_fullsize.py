@@ -1,0 +1,158 @@
+"""-m gpu: the HIP path at BASELINE config 2's FULL sizes (B=32, T=500, d=768, H=8, dh=96, V=10000), where the numpy
+oracle would take minutes: checked through size-independent properties of the domain instead -
+rows of attention weights sum to one, a CTC gradient frame sums to zero, LayerNorm rows are standardised, GEMM is
+linear, the forward pass is deterministic, and the mean of tower gradients equals the full-batch gradient (the
+reference's data-parallel rule, gradientTools.py:7-37).  torch is used here only to CHECK device buffers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from neurst_amd.synthetic import make_batch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from neurst_amd import ops
+    DEV = torch.device('cuda:0')
+
+B, H, T, DH, D, V = 32, 8, 500, 96, 768, 10000
+
+
+def test_attention_rows_sum_to_one_and_dropout_keeps_the_mean():
+    g = torch.Generator(device='cpu').manual_seed(1)
+    qkv = (torch.randn(B, T, 3 * D, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    qkv[:, :, 2 * D:] = 1.0                                  # V = ones: O = sum_j P_ij = 1 for every query
+    lens = torch.from_numpy(np.random.default_rng(0).integers(T // 2, T + 1, size=B).astype(np.int32)).to(DEV)
+    t = qkv.view(-1)
+    o, lse = ops.mha_fwd(t, t[D:], t[2 * D:], 3 * D, 3 * D, 3 * D, B, H, T, T, DH, ops.MASK_KEYPAD, lens, 0.0, 7)
+    assert torch.isfinite(lse).all()
+    assert (o.float() - 1.0).abs().max().item() < 1e-2        # bf16 probabilities: 2^-8 relative each
+    o2, lse2, kb = ops.mha_fwd(t, t[D:], t[2 * D:], 3 * D, 3 * D, 3 * D, B, H, T, T, DH, ops.MASK_KEYPAD, lens, 0.1, 7, keep_bits=True)
+    assert abs(o2.float().mean().item() - 1.0) < 2e-3         # E[keep / (1 - rate)] = 1
+    # the stored decisions are the recomputed ones: backward with and without them gives the same gradients
+    do = torch.randn_like(o2)
+    outs = []
+    for bits in (kb, None):
+        dqkv = torch.zeros_like(qkv)
+        dt = dqkv.view(-1)
+        ops.mha_bwd(t, t[D:], t[2 * D:], o2, do, lse2, dt, dt[D:], dt[2 * D:], 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, B, H, T, T, DH,
+                    ops.MASK_KEYPAD, lens, 0.1, 7, keep_bits=bits)
+        outs.append(dqkv)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_ctc_gradient_frames_sum_to_zero_and_padding_is_zero():
+    rng = np.random.default_rng(3)
+    logits = torch.randn(B, T, V, device=DEV) * 2.0
+    len_logits = torch.from_numpy(rng.integers(T // 2, T + 1, size=B).astype(np.int32)).to(DEV)
+    U = 40
+    labels = torch.from_numpy(rng.integers(4, V - 1, size=(B, U)).astype(np.int32)).to(DEV)
+    len_labels = torch.from_numpy(rng.integers(U // 2, U + 1, size=B).astype(np.int32)).to(DEV)
+    ref_argmax = logits.argmax(-1).int()
+    loss, grad, argmax = ops.ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, ops.F32, 1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all() and (loss > 0).all()
+    pad = torch.arange(T, device=DEV)[None, :] >= len_logits[:, None]
+    valid = ~pad
+    assert torch.equal(argmax[valid], ref_argmax[valid])      # frames past the length report the blank
+    frame_sum = grad.sum(-1)                                  # softmax - posterior: both sum to one over the vocabulary
+    assert frame_sum.abs().max().item() < 5e-4
+    assert grad[pad].abs().max().item() == 0.0
+    assert (grad[valid].abs().sum(-1) > 0).all()
+
+
+def test_layernorm_rows_are_standardised_and_backward_is_orthogonal():
+    rows = B * T
+    x = (torch.randn(rows, D, device=DEV) * 3 + 1).to(torch.bfloat16)
+    y = torch.randn(rows, D, device=DEV).to(torch.bfloat16)
+    gamma, beta = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    out, mean, rstd = ops.dropout_add_layernorm_fwd(x, y, gamma, beta, 0.0, 5)
+    o = out.float()
+    assert o.mean(-1).abs().max().item() < 2e-2 and (o.var(-1, unbiased=False) - 1).abs().max().item() < 3e-2
+    # d/dz of LN is orthogonal to the constant vector and to x-hat: rows of dz sum to ~0 and are ~uncorrelated with out
+    dout = torch.randn(rows, D, device=DEV).to(torch.bfloat16)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dz, _ = ops.dropout_add_layernorm_bwd(dout, y, gamma, mean, rstd, dg, db, 0.0, 5)
+    dzf = dz.float()
+    scale = dzf.abs().mean().item()
+    assert dzf.mean(-1).abs().max().item() < 2e-2 * scale * 10
+    assert (dzf * o).mean(-1).abs().max().item() < 5e-2 * scale * 10
+    assert torch.allclose(db, dout.float().sum(0), rtol=1e-3, atol=1e-2)      # dbeta = column sums (atomics from 256 workgroups)
+    assert torch.allclose(dg, (dout.float() * o).sum(0), rtol=2e-2, atol=2.0)
+
+
+@pytest.mark.parametrize('ta,tb,M,N,K', [(0, 1, 16000, 2304, 768), (0, 0, 16000, 768, 3072), (1, 0, 3072, 768, 16000)])
+def test_gemm_is_linear_in_its_operand(ta, tb, M, N, K):
+    """operands on a 1/8 grid are exact in bf16 and their products/sums exact in fp32: C(A, B1 + B2) == C(A, B1) + C(A, B2)"""
+    rng = np.random.default_rng(K)
+    grid = lambda *s: torch.from_numpy(rng.integers(-8, 9, size=s).astype(np.float32) / 8).to(DEV).to(torch.bfloat16)
+    A = grid(K, M) if ta else grid(M, K)
+    B1, B2 = (grid(N, K), grid(N, K)) if tb else (grid(K, N), grid(K, N))
+    B12 = (B1.float() + B2.float()).to(torch.bfloat16)
+    assert torch.equal(B12.float(), B1.float() + B2.float())
+    outs = []
+    for Bm in (B1, B2, B12):
+        C = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+        sk = ops.pick_split_k(M, N, K) if ta else 1
+        ops.gemm(A, Bm, C, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, accumulate=sk > 1, split_k=sk)
+        outs.append(C)
+    assert torch.equal(outs[0] + outs[1], outs[2])            # every partial sum is a multiple of 1/64 below 2^24: exact
+
+
+def _lut_model(num_blocks=None, dropout=None, dtype='bf16', V_=V):
+    from neurst_amd.st.layers.arguments import build_args, load_config
+    from neurst_amd.st.models.TransformerTPE import GlobalStep
+    cfg = load_config(os.path.join(ge.ROOT, 'configs', 'lut.yaml'))
+    for part in ('encoder', 'encoder2', 'decoder'):
+        if num_blocks:
+            cfg['model'][part]['num_blocks'] = num_blocks
+        if dropout is not None:
+            cfg['model'][part]['attention_dropout_rate'] = dropout
+            cfg['model'][part]['residual_dropout_rate'] = dropout
+    if dropout is not None:
+        cfg['model']['kd']['attention_dropout_rate'] = dropout
+    cfg['beam_size'] = 1
+    args = build_args(cfg, dim_output=V_, compute_dtype=dtype)
+    return args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args), args
+
+
+def test_config2_forward_is_deterministic_and_gradients_reproduce():
+    """BASELINE config 2 as bench.py runs it (dropout 0.1, counter-based masks): the same step twice gives bit-identical
+    losses (no atomics on the forward path) and gradients that differ only by fp32 atomic-add ordering."""
+    model, _ = _lut_model()
+    batch = make_batch(B=B, Traw=1500, V=V, L=40, U=40, Lb=40, bert_dim=768, seed=11, ragged=True)
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in batch.items()}
+    a = model.forward_backward(batch).clone()
+    ga = model.store.grads.clone()
+    b = model.forward_backward(batch).clone()
+    gb = model.store.grads
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.isfinite(ga).all()
+    den = ga.norm().item()
+    assert den > 0 and (ga - gb).norm().item() < 1e-4 * den
+
+
+def test_mean_of_tower_gradients_equals_full_batch_gradient():
+    """gradientTools.py:7-37 / lstmModel.py:342-350: the batch is split into equal towers after padding and the tower
+    gradients are averaged.  Two half-batch passes through the same kernels must reproduce the full-batch gradient
+    (dropout off; LUT widths, 2 blocks each, bf16: agreement to bf16 rounding of the activations)."""
+    model, _ = _lut_model(num_blocks=2, dropout=0.0, V_=1000)
+    Bt = 8
+    host = make_batch(B=Bt, Traw=600, V=1000, L=20, U=16, Lb=12, bert_dim=768, seed=5, ragged=True)
+    dev = {k: torch.from_numpy(v).to(DEV) for k, v in host.items()}
+    full_loss = model.forward_backward(dev).clone()
+    full = model.store.grads.clone()
+    acc = torch.zeros_like(full)
+    losses = []
+    for h in range(2):
+        half = {k: v[h * Bt // 2:(h + 1) * Bt // 2].contiguous() for k, v in dev.items()}
+        losses.append(model.forward_backward(half).clone())
+        acc += model.store.grads
+    acc *= 0.5
+    assert torch.allclose((losses[0] + losses[1]) * 0.5, full_loss, rtol=2e-3, atol=1e-3), (losses, full_loss)
+    rel = (acc - full).norm().item() / full.norm().item()
+    cos = torch.dot(acc, full).item() / (acc.norm().item() * full.norm().item())
+    assert rel < 2e-2 and cos > 0.9995, (rel, cos)
