@@ -98,6 +98,16 @@ class VariableStore:
         self.params.copy_(torch.from_numpy(host))
         self.sync_shadow()
 
+    def load_slots(self, m_named, v_named):
+        """Adam first / second moments by variable name (checkpoint restore)."""
+        for arena, named in ((self.m, m_named), (self.v, v_named)):
+            host = arena.cpu().numpy()
+            for name, arr in named.items():
+                p = self.vars[name]
+                assert tuple(arr.shape) == p.shape, (name, arr.shape, p.shape)
+                host[p.offset:p.offset + p.size] = np.asarray(arr, np.float32).reshape(-1)
+            arena.copy_(torch.from_numpy(host))
+
     def export(self, arena=None):
         host = (self.params if arena is None else arena).float().cpu().numpy()
         return {n: host[p.offset:p.offset + p.size].reshape(p.shape).copy() for n, p in self.vars.items()}

@@ -1,0 +1,132 @@
+"""Checkpoints of the variable store under the reference's TF variable names and layouts - SURVEY 8(f) rank 1, partial.
+
+Mirrors the reading interface of st/tools/tftools/checkpointTools.py:44-97 (`load_checkpoint(...).get_tensor`,
+`load_variable`, `list_variables`), what `tf.train.Saver` keeps for this model (`st/bin/run_lut.py:140-276`: variables,
+Adam slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power`, `global_step`) and st/tools/avg_checkpoints.py:46-117.
+
+Container: ONE numpy `.npz` (plain arrays, read with allow_pickle=False) - NOT TensorFlow's TensorBundle
+(`.index` / `.data-*`): no reference checkpoint exists in the repository to pin a bundle parser against, so that
+importer is left for a later round.  Variable names and array layouts are the TF ones (`[out, in]` for `dense`,
+`[in, out]` for `tf.layers.dense` kernels), so a bundle importer only has to produce this dict."""
+import os
+
+import numpy as np
+
+ADAM_M, ADAM_V = '/Adam', '/Adam_1'
+
+
+class CheckpointReader:
+    """Subset of pywrap_tensorflow.CheckpointReader used by the reference (get_tensor, get_variable_to_shape_map)."""
+
+    def __init__(self, path):
+        self.path = resolve(path)
+        self._z = np.load(self.path, allow_pickle=False)
+
+    def get_tensor(self, name):
+        name = name[:-2] if name.endswith(':0') else name
+        return np.array(self._z[name])
+
+    def has_tensor(self, name):
+        return name in self._z.files
+
+    def get_variable_to_shape_map(self):
+        return {k: list(self._z[k].shape) for k in self._z.files}
+
+
+def resolve(ckpt_dir_or_file):
+    """A directory means its newest checkpoint (tf.train.latest_checkpoint): the last line of `<dir>/checkpoint`."""
+    if os.path.isdir(ckpt_dir_or_file):
+        index = os.path.join(ckpt_dir_or_file, 'checkpoint')
+        if not os.path.exists(index):
+            raise ValueError("Couldn't find 'checkpoint' file or checkpoints in given directory %s" % ckpt_dir_or_file)
+        names = [l.strip() for l in open(index) if l.strip()]
+        return os.path.join(ckpt_dir_or_file, names[-1])
+    return ckpt_dir_or_file if ckpt_dir_or_file.endswith('.npz') else ckpt_dir_or_file + '.npz'
+
+
+def load_checkpoint(ckpt_dir_or_file):
+    return CheckpointReader(ckpt_dir_or_file)
+
+
+def load_variable(ckpt_dir_or_file, name):
+    return load_checkpoint(ckpt_dir_or_file).get_tensor(name)
+
+
+def list_variables(ckpt_dir_or_file):
+    m = load_checkpoint(ckpt_dir_or_file).get_variable_to_shape_map()
+    return [(k, m[k]) for k in sorted(m)]
+
+
+def save_checkpoint(path, store, global_step, beta1=0.9, beta2=0.98, slots=True):
+    """Writes `<path>.npz` (variables, Adam slots, beta powers, global_step) and appends it to `<dir>/checkpoint`."""
+    out = store.export()
+    if slots:
+        for k, v in store.export(store.m).items():
+            out[k + ADAM_M] = v
+        for k, v in store.export(store.v).items():
+            out[k + ADAM_V] = v
+        out['beta1_power'] = np.float32(beta1 ** max(store.adam_t, 0) * beta1)   # TF keeps beta^(t+1)
+        out['beta2_power'] = np.float32(beta2 ** max(store.adam_t, 0) * beta2)
+        out['adam_t'] = np.int64(store.adam_t)
+    out['global_step'] = np.int64(int(global_step))
+    full = resolve(path)
+    os.makedirs(os.path.dirname(os.path.abspath(full)), exist_ok=True)
+    np.savez(full, **out)
+    with open(os.path.join(os.path.dirname(os.path.abspath(full)), 'checkpoint'), 'a') as f:
+        f.write(os.path.basename(full) + '\n')
+    return full
+
+
+def restore(ckpt_dir_or_file, store, assignment_map=None, slots=True, strict=True):
+    """Loads variables (and Adam slots) into the store; returns the checkpoint's global_step.
+    assignment_map {'checkpoint_scope/': 'scope/'} renames prefixes as `init_from_checkpoint` does (:100-160)."""
+    r = load_checkpoint(ckpt_dir_or_file)
+
+    def ckpt_name(var):
+        for src, dst in (assignment_map or {}).items():
+            dst = '' if dst == '/' else dst
+            src = '' if src == '/' else src
+            if var.startswith(dst):
+                return src + var[len(dst):]
+        return var
+
+    params, m, v, missing = {}, {}, {}, []
+    for name, p in store.vars.items():
+        cn = ckpt_name(name)
+        if not r.has_tensor(cn):
+            missing.append(name)
+            continue
+        arr = r.get_tensor(cn)
+        if tuple(arr.shape) != p.shape:
+            raise ValueError('Shape of variable %s (%s) does not match the checkpoint tensor %s (%s)' % (name, p.shape, cn, arr.shape))
+        params[name] = arr
+        if slots and r.has_tensor(cn + ADAM_M) and r.has_tensor(cn + ADAM_V):
+            m[name], v[name] = r.get_tensor(cn + ADAM_M), r.get_tensor(cn + ADAM_V)
+    if missing and strict:
+        raise ValueError('variables missing from %s: %s' % (r.path, ', '.join(missing[:5]) + (' ...' if len(missing) > 5 else '')))
+    store.load_params(params)
+    if slots and m:
+        store.load_slots(m, v)
+        if r.has_tensor('adam_t'):
+            store.adam_t = int(r.get_tensor('adam_t'))
+    return int(r.get_tensor('global_step')) if r.has_tensor('global_step') else 0
+
+
+def average_checkpoints(checkpoints, output_path):
+    """st/tools/avg_checkpoints.py:75-117: element-wise mean of every variable except global_step (Adam slots included,
+    as the reference's list_variables loop does); the result carries global_step 0."""
+    checkpoints = [c for c in checkpoints if os.path.exists(resolve(c))]
+    if not checkpoints:
+        raise ValueError('None of the provided checkpoints exist.')
+    names = [n for n, _ in list_variables(checkpoints[0]) if not n.startswith('global_step') and n != 'adam_t']
+    acc = {}
+    for c in checkpoints:
+        r = load_checkpoint(c)
+        for n in names:
+            t = r.get_tensor(n).astype(np.float64)
+            acc[n] = t if n not in acc else acc[n] + t
+    out = {n: (a / len(checkpoints)).astype(np.float32) for n, a in acc.items()}
+    out['global_step'] = np.int64(0)
+    full = resolve(output_path)
+    np.savez(full, **out)
+    return full

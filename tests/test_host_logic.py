@@ -173,3 +173,39 @@ def test_grad_bucketer_two_rank_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_checkpoint_roundtrip_rename_and_average(tmp_path):
+    """.npz checkpoints under the TF variable names - save / list / load_variable / restore with a
+    scope rename / average (st/tools/tftools/checkpointTools.py:44-97, st/tools/avg_checkpoints.py:75-117)."""
+    import torch
+    from neurst_amd import ops
+    from neurst_amd.st.models.graph import VariableStore
+    from neurst_amd.st.tools.tftools import checkpointTools as ck
+    specs = [('transformer/encoder/encoder_fc/kernel', (6, 4), 'glorot'), ('transformer/encoder/block_0/layer_norm/layer_norm_scale', (4,), 'ones'),
+             ('transformer/decoder/decoder_fc/kernel', (4, 7), 'glorot')]
+    a = VariableStore(specs, torch.device('cpu'), ops.F32, seed=3)
+    a.m += 0.25
+    a.v += 0.5
+    a.adam_t = 7
+    p1 = ck.save_checkpoint(str(tmp_path / 'model-100'), a, 100)
+    assert [n for n, _ in ck.list_variables(p1) if n.endswith('kernel')] == ['transformer/decoder/decoder_fc/kernel', 'transformer/encoder/encoder_fc/kernel']
+    assert ck.load_variable(p1, 'transformer/encoder/encoder_fc/kernel:0').shape == (6, 4)
+    assert ck.resolve(str(tmp_path)) == p1                     # directory -> newest checkpoint
+    b = VariableStore(specs, torch.device('cpu'), ops.F32, seed=9)
+    assert ck.restore(str(tmp_path), b) == 100 and b.adam_t == 7
+    for arena in ('params', 'm', 'v'):               # by variable: the alignment padding between variables is not saved
+        ea, eb = a.export(getattr(a, arena)), b.export(getattr(b, arena))
+        assert all(np.array_equal(ea[k], eb[k]) for k in ea)
+    # a model built under another name loads it through an assignment map
+    c = VariableStore([(n.replace('transformer/', 'student/'), s, k) for n, s, k in specs], torch.device('cpu'), ops.F32, seed=1)
+    ck.restore(p1, c, assignment_map={'transformer/': 'student/'})
+    assert all(np.array_equal(v, c.export()[k.replace('transformer/', 'student/')]) for k, v in a.export().items())
+    with pytest.raises(ValueError):
+        ck.restore(p1, c)                                      # without the map the names do not match
+    a.params *= 3.0
+    p2 = ck.save_checkpoint(str(tmp_path / 'model-200'), a, 200)
+    avg = ck.average_checkpoints([p1, p2, str(tmp_path / 'missing')], str(tmp_path / 'averaged'))
+    d = VariableStore(specs, torch.device('cpu'), ops.F32, seed=5)
+    assert ck.restore(avg, d) == 0
+    assert all(np.allclose(v, 2.0 * b.export()[k]) for k, v in d.export().items())
