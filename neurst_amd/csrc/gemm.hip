@@ -43,13 +43,16 @@ __device__ __forceinline__ typename Chunk<T>::V load_chunk(const T* __restrict__
 // bf16 tiles are unpadded and XOR-swizzled at 16-byte granularity so that both ds_read_b128 row reads
 // (128-B rows: chunk ^= row&7) and ds_read_b64_tr_b16 (256-B rows: chunk ^= ((row&3)<<2)|((row>>2)&3),
 // cdna_hip_programming.md T10 image (b)) are bank-conflict free; fp32 (parity mode) tiles are padded.
-template <typename T, bool TRANS, int BKT = GemmCfg<T>::BK>
+template <typename T, bool TRANS, int BKT = GemmCfg<T>::BK, int ROWS = 128>
 struct Stager {
+  // ROWS = rows of the output dimension in the tile: 128, or 32 for the A side of the thin-tile variant (K-contiguous only)
+  static_assert(ROWS == 128 || !TRANS, "k-strided tiles are 128 wide");
   static constexpr int BK = BKT, EPC = GemmCfg<T>::EPC;
   static constexpr bool SWZ = sizeof(T) == 2;
   static constexpr int LD = SWZ ? (TRANS ? 128 : BK) : (TRANS ? GemmCfg<T>::LDT : GemmCfg<T>::LDK);
-  static constexpr int TILE = (TRANS ? BK : 128) * LD;   // elements
-  static constexpr int NCH = 128 * BK / EPC / NT;
+  static constexpr int TILE = (TRANS ? BK : ROWS) * LD;   // elements
+  static constexpr int NCH = ROWS * BK / EPC / NT;
+  static_assert(NCH >= 1, "tile smaller than one 16-byte chunk per thread");
   static constexpr int CPR = TRANS ? 128 / EPC : BK / EPC;   // chunks per LDS row
   typename Chunk<T>::V reg[NCH];
 
@@ -118,10 +121,10 @@ template <> __device__ __forceinline__ bf16x8 ones_frag<bf16_t>() {
 // applied to the SOURCE chunk each lane fetches (cdna_hip_programming.md 5.4 rule 21).  Rows of the
 // output dimension beyond R are clamped to a valid address: they only feed output rows/columns that the
 // epilogue never stores.  The reduction range of the tile must be fully in bounds.
-template <typename T, bool TRANS, int BKT>
+template <typename T, bool TRANS, int BKT, int ROWS = 128>
 __device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R,
                                            T* __restrict__ S, int tid) {
-  typedef Stager<T, TRANS, BKT> St;
+  typedef Stager<T, TRANS, BKT, ROWS> St;
 #pragma unroll
   for (int i = 0; i < St::NCH; ++i) {
     const int P = tid + i * NT;                      // 16-byte chunk position in the LDS tile
@@ -144,28 +147,30 @@ __device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t l
   }
 }
 
-template <typename T, typename SA, typename SB, int SUMOP>
-__device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __restrict__ Bc, f32x4 (&acc)[4][4], f32x4 (&sacc)[4], bool duty,
+template <typename T, typename SA, typename SB, int SUMOP, int MI = 4>
+__device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __restrict__ Bc, f32x4 (&acc)[MI][4], f32x4 (&sacc)[4], bool duty,
                                          int wm, int wn, int lane) {
+  // MI = 16-row MFMA tiles per wave along M: 4 (64 x 64 wave tile) or 1 (16 x 64, thin-tile variant)
+  static_assert(MI == 4 || SUMOP == 0, "operand sums ride on the 64 x 64 wave tile");
   constexpr int BK = SA::BK, KS = Mma<T>::KS;
   typename Mma<T>::Frag sel = ones_frag<T>();
   if (!duty) sel = sel - sel;
 #pragma unroll
   for (int ks = 0; ks < BK; ks += KS) {
-    typename Mma<T>::Frag af[4], bf[4];
+    typename Mma<T>::Frag af[MI], bf[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = SA::frag(Ac, wm * 64 + i * 16, ks, lane);
+    for (int i = 0; i < MI; ++i) af[i] = SA::frag(Ac, wm * (16 * MI) + i * 16, ks, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[j] = SB::frag(Bc, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
     // the sum rides on the fragments already in registers: one more MFMA per fragment against ones (duty) or
     // zeros (not duty) - branch-free, so the register allocation of the main loop is unchanged
     if constexpr (SUMOP == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sacc[i] = Mma<T>::mma(af[i], sel, sacc[i]);
+      for (int i = 0; i < MI; ++i) sacc[i] = Mma<T>::mma(af[i], sel, sacc[i]);
     } else if constexpr (SUMOP == 2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) sacc[j] = Mma<T>::mma(sel, bf[j], sacc[j]);
@@ -469,24 +474,24 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
 constexpr int PEPI_LD = 36;                                   // fp32 row stride of a 16 x 32 staging half-tile
 constexpr int PEPI_BYTES = 4 * 16 * PEPI_LD * 4;              // one per wave
 
-template <typename T, typename TC>
-__device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], const float (&bcol)[4], float* __restrict__ Cs,
+template <typename T, typename TC, int MI = 4>
+__device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], const float (&bcol)[4], float* __restrict__ Cs,
                                                  int64_t wrow0, int64_t wcol0, int lane) {
   TC* C = reinterpret_cast<TC*>(g.C);
   const T* rs = reinterpret_cast<const T*>(g.relu_src);
   const int lg = lane >> 4, l15 = lane & 15;
   const int rr = lane >> 2, cc = (lane & 3) * 8;
   // relu-gradient gate: all eight chunks this lane needs are requested up front (one wait instead of eight)
-  typename Chunk<T>::V gate[8];
+  typename Chunk<T>::V gate[2 * MI];
   if (rs) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < 2 * MI; ++p) {
       const int64_t row = wrow0 + (p >> 1) * 16 + rr, col = wcol0 + (p & 1) * 32 + cc;
       if (row < g.M && g.c_vec && col + 8 <= g.N) gate[p] = *reinterpret_cast<const typename Chunk<T>::V*>(rs + row * g.ldc + col);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
       // 16 rows x 32 columns of the wave's tile: MFMA layout -> LDS -> 8 consecutive columns per lane
@@ -632,6 +637,100 @@ __global__ void __launch_bounds__(NT) gemm_persist_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------- thin-tile variant for the smallest grids
+// A decoder-size problem (M = 1280 rows, N = 768) has 60 tiles of 128 x 128: 60 of 256 CUs work, and each of their waves
+// issues 64 MFMAs per K-step, so the K loop (12 - 156 steps) is a serial chain of ~0.45 us links.  32 x 128 tiles (wave
+// tile 16 x 64) put 240 workgroups on the chip with 16 MFMAs per wave and K-step.  Same 4-stage direct-to-LDS pipeline
+// as the small-grid path of gemm_kernel; A is K-contiguous (NT / NN).
+template <typename TC, bool TB_KCONTIG>
+__global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
+  typedef bf16_t T;
+  constexpr int BK = 64, NS = 4, BMT = 32;
+  typedef Stager<T, false, BK, BMT> SA;
+  typedef Stager<T, !TB_KCONTIG, BK> SB;
+  constexpr int STAGE_BYTES = NS * (SA::TILE + SB::TILE) * (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + PEPI_BYTES];
+  T* const lds = reinterpret_cast<T*>(smem);
+  auto As = [&](int b) -> T* { return lds + b * SA::TILE; };
+  auto Bs = [&](int b) -> T* { return lds + NS * SA::TILE + b * SB::TILE; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* const Cs = reinterpret_cast<float*>(smem + STAGE_BYTES) + wave * 16 * PEPI_LD;
+  // row tiles fastest: the workgroups that share one 128-column panel of B are neighbours
+  const int tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;
+  const int64_t m0 = (int64_t)tm * BMT, n0 = (int64_t)tn * BN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+  f32x4 acc[1][4], sacc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bcol[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 16 + (lane & 15);
+      bcol[j] = col < g.N ? g.bias[col] : 0.f;
+    }
+  }
+  const int nfull = (int)(g.K / BK);
+  constexpr int LPT = SA::NCH + SB::NCH;
+  static_assert(LPT * (NS - 2) <= 63, "vmcnt field");
+  // the bias loads above are older than every tile load: the counted waits below cover them too
+  const int npro = nfull < NS - 1 ? nfull : NS - 1;
+  for (int t = 0; t < npro; ++t) {
+    issue_glds<T, false, BK, BMT>(A, g.lda, m0, (int64_t)t * BK, g.M, As(t), tid);
+    issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, (int64_t)t * BK, g.N, Bs(t), tid);
+  }
+  int cur = 0;
+  for (int it = 0; it < nfull; ++it) {
+    const int issued = it + NS - 1 < nfull ? it + NS - 1 : nfull;
+    const int inflight = issued - it - 1;          // tiles newer than `it` already issued: 0 .. NS-2
+    if (inflight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * 2) : "memory");
+    else if (inflight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // every wave's share of tile `it` is in LDS; buffer (it-1)%NS is free
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + NS - 1 < nfull) {
+      const int nb = (cur + NS - 1) % NS;
+      const int64_t kn = (int64_t)(it + NS - 1) * BK;
+      issue_glds<T, false, BK, BMT>(A, g.lda, m0, kn, g.M, As(nb), tid);
+      issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kn, g.N, Bs(nb), tid);
+    }
+    mma_tile<T, SA, SB, 0, 1>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
+    cur = (cur + 1) % NS;
+  }
+  const int64_t ktail = (int64_t)nfull * BK;
+  if (ktail < g.K) {   // partial K-tile: register staging with zero fill (as in gemm_kernel)
+    SA sa;
+    SB sb;
+    sa.load(A, g.lda, m0, ktail, g.M, g.K, true, tid);
+    sb.load(B, g.ldb, n0, ktail, g.N, g.K, true, tid);
+    __syncthreads();
+    sa.store(As(cur), tid);
+    sb.store(Bs(cur), tid);
+    __syncthreads();
+    mma_tile<T, SA, SB, 0, 1>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
+  }
+  persist_epilogue<T, TC, 1>(g, acc, bcol, Cs, m0 + wm * 16, n0 + wn * 64, lane);
+}
+
+static int thin_max_tiles() {
+  static const int v = [] { const char* e = getenv("NEURST_GEMM_THIN_MAX_TILES"); return e ? atoi(e) : 64; }();
+  return v;
+}
+// true if the launch was taken by the thin-tile kernel: K-contiguous A, at most thin_max_tiles() tiles of 128 x 128
+template <typename TC>
+static bool launch_gemm_thin(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
+  if (trans_a || g.split_k != 1 || g.K < 256) return false;
+  if ((int64_t)g.tiles_m * g.tiles_n > thin_max_tiles()) return false;
+  GemmArgs t = g;
+  t.tiles_m = (int)cdiv64(g.M, 32);
+  const int grid = t.tiles_m * t.tiles_n;
+  if (trans_b) gemm_thin_kernel<TC, true><<<grid, NT, 0, s>>>(t);
+  else gemm_thin_kernel<TC, false><<<grid, NT, 0, s>>>(t);
+  return true;
+}
+
 static int persist_min_tiles() {
   static const int v = [] { const char* e = getenv("NEURST_GEMM_PERSIST_MIN_TILES"); return e ? atoi(e) : 1024; }();
   return v;
@@ -665,7 +764,10 @@ static int launch_gemm_ns(const GemmArgs& g, int trans_a, int trans_b, hipStream
 template <typename T, typename TC, bool FAST>
 static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
   if constexpr (FAST) {
-    if (small_grid(g)) return launch_gemm_ns<T, TC, true, 4>(g, trans_a, trans_b, s);
+    if (small_grid(g)) {
+      if (launch_gemm_thin<TC>(g, trans_a, trans_b, s)) return 0;
+      return launch_gemm_ns<T, TC, true, 4>(g, trans_a, trans_b, s);
+    }
     if (launch_gemm_persist<TC>(g, trans_a, trans_b, s)) return 0;
   }
   return launch_gemm_ns<T, TC, FAST, 2>(g, trans_a, trans_b, s);

@@ -160,6 +160,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias=None, relu=Fals
     return C
 
 
+THIN_MAX_TILES = int(os.environ.get('NEURST_GEMM_THIN_MAX_TILES', '64'))         # csrc/gemm.hip: thin_max_tiles()
 PERSIST_MIN_TILES = int(os.environ.get('NEURST_GEMM_PERSIST_MIN_TILES', '1024'))   # csrc/gemm.hip: persist_min_tiles()
 
 
@@ -172,6 +173,8 @@ def gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, split_k=1, bias_grad=Fals
     fast = ab == 'bf16' and K % 8 == 0 and (not trans_a or M % 8 == 0) and (trans_b or N % 8 == 0)
     tiles = -(-M // 128) * -(-N // 128) * max(split_k, 1)
     ns = 4 if (fast and tiles <= 256 and K >= 256) else 2
+    if ns == 4 and not trans_a and split_k <= 1 and not bias_grad and tiles <= THIN_MAX_TILES:
+        return 'gemm_thin_kernel<bf16,%s,%s>' % (c, lay)
     if fast and lay == 'NT' and ns == 2 and split_k <= 1 and not bias_grad and K % 64 == 0 and K >= 192 and tiles >= PERSIST_MIN_TILES:
         return 'gemm_persist_kernel<%s,%s,NT>' % (ab, c)
     return 'gemm_kernel<%s,%s,%s,%s,stages=%d%s>' % (ab, c, lay, 'direct-to-LDS' if fast else 'register-staged', ns, ',+bias-grad' if bias_grad else '')

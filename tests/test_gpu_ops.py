@@ -107,6 +107,34 @@ def test_gemm_persistent_many_tiles(ta, tb, M, N, K, cdt):
         assert relerr(host(C3), ref * (gate > 0)) < tol
 
 
+@pytest.mark.parametrize('tb', [1, 0])
+@pytest.mark.parametrize('M,N,K,cdt', [(1280, 768, 768, 'bf16'), (1280, 768, 3072, 'bf16'), (70, 136, 256, 'bf16'), (333, 520, 640, 'f32'),
+                                       (1280, 768, 10000, 'bf16'), (96, 128, 8 * 37, 'f32')])
+def test_gemm_thin_tiles(tb, M, N, K, cdt):
+    """aligned bf16 problems with K-contiguous A and at most 64 tiles of 128 x 128 take the 32 x 128-tile
+    kernel: ragged edges, a partial last K-tile, bias + relu, accumulate and the relu-gradient gate."""
+    rng = np.random.default_rng(M + K + tb)
+    A = bf16_round(rng.standard_normal((M, K)))
+    B = bf16_round(rng.standard_normal((N, K) if tb else (K, N)))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    tc = torch.bfloat16 if cdt == 'bf16' else torch.float32
+    tol = 1e-2 if cdt == 'bf16' else 1e-5
+    dA, dB = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    for rep in range(3):
+        C = torch.empty((M, N), dtype=tc, device=DEV)
+        ops.gemm(dA, dB, C, M, N, K, K, B.shape[1], N, 0, tb, bias=dev(bias))
+        assert relerr(host(C), ref + bias) < tol, rep
+    C2 = torch.full((M, N), 0.5, dtype=tc, device=DEV)
+    ops.gemm(dA, dB, C2, M, N, K, K, B.shape[1], N, 0, tb, bias=dev(bias), relu=True, accumulate=True)
+    assert relerr(host(C2), np.maximum(ref + bias, 0) + 0.5) < tol
+    if cdt == 'bf16':
+        gate = bf16_round(rng.standard_normal((M, N)))
+        C3 = torch.empty((M, N), dtype=tc, device=DEV)
+        ops.gemm(dA, dB, C3, M, N, K, K, B.shape[1], N, 0, tb, relu_src=dev(gate, torch.bfloat16))
+        assert relerr(host(C3), ref * (gate > 0)) < tol
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_gemm_splitk_and_relu_gate(dtype):
     rng = np.random.default_rng(5)

@@ -21,6 +21,9 @@ def gemm_label(name):
     if mp:
         lay = {('0', '1'): 'NT', ('0', '0'): 'NN', ('1', '0'): 'TN'}[mp.groups()[1:]]
         return 'gemm_persist_kernel<bf16,%s,%s>' % ('bf16' if mp.group(1) == 'DF16b' else 'f32', lay)
+    mt = re.match(r'_Z16gemm_thin_kernelI(DF16b|f)Lb([01])EEv8GemmArgs', name)
+    if mt:
+        return 'gemm_thin_kernel<bf16,%s,%s>' % ('bf16' if mt.group(1) == 'DF16b' else 'f32', 'NT' if mt.group(2) == '1' else 'NN')
     m = re.match(r'_Z11gemm_kernelI(DF16b|f)(DF16b|f)Lb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)EEv8GemmArgs', name)
     if m:
         t, tc, ta, tbk, fast, sumop, ns = m.groups()
