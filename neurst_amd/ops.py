@@ -21,6 +21,20 @@ def L():
     return _L
 
 
+class _Symbols:
+    """C entry points as plain instance attributes after their first use (an attribute read instead of a call to L() and
+    a ctypes symbol lookup on every launch: the wrappers below run ~300 times per train step)."""
+
+    def __getattr__(self, name):
+        fn = getattr(L(), name)
+        setattr(self, name, fn)
+        return fn
+
+
+_C = _Symbols()
+_DT = {torch.bfloat16: BF16, torch.float32: F32}
+
+
 def _s():
     """Raw hipStream_t the next launch goes to: the stream set by `on_stream`, else torch's current stream (the C-level
     query: ~0.2 us instead of ~4 us through torch.cuda.Stream)."""
@@ -112,7 +126,7 @@ def splice_downsample(x, len_raw, num_context, rate, out_dtype):
     Tout = -(-Traw // rate)
     out = torch.empty((B, Tout, F * (num_context + 1)), dtype=torch_dtype(out_dtype), device=x.device)
     len_out = torch.empty_like(len_raw)
-    _chk(L().neurst_splice_downsample(_p(_c(x)), _p(len_raw), _p(out), _p(len_out), B, Traw, F, num_context, rate, out_dtype, _s()),
+    _chk(_C.neurst_splice_downsample(_p(_c(x)), _p(len_raw), _p(out), _p(len_out), B, Traw, F, num_context, rate, out_dtype, _s()),
          'splice_downsample')
     return out, len_out
 
@@ -121,13 +135,13 @@ def splice_downsample(x, len_raw, num_context, rate, out_dtype):
 def specaug_params(x, F, Tmax, p, key):
     B, T, v = x.shape
     params = torch.empty((B, 8), dtype=torch.int32, device=x.device)
-    _chk(L().neurst_specaug_params(_p(_c(x)), _p(params), B, T, v, F, Tmax, p, key, _s()), 'specaug_params')
+    _chk(_C.neurst_specaug_params(_p(_c(x)), _p(params), B, T, v, F, Tmax, p, key, _s()), 'specaug_params')
     return params
 
 
 def specaug_apply_(x, params):
     B, T, v = x.shape
-    _chk(L().neurst_specaug_apply(_p(_c(x)), _p(_c(params)), B, T, v, _s()), 'specaug_apply')
+    _chk(_C.neurst_specaug_apply(_p(_c(x)), _p(_c(params)), B, T, v, _s()), 'specaug_apply')
     return x
 
 
@@ -136,27 +150,30 @@ def add_timing_dropout(x, out_dtype, rate, key):
     B, T, C = x.shape
     y = torch.empty((B, T, C), dtype=torch_dtype(out_dtype), device=x.device)
     sig = timing_signal_table(T, C, x.device)
-    _chk(L().neurst_add_timing_dropout_fwd(_p(_c(x)), dt_of(x), _p(sig), _p(y), out_dtype, B, T, C, rate, key, _s()), 'add_timing_dropout')
+    _chk(_C.neurst_add_timing_dropout_fwd(_p(_c(x)), dt_of(x), _p(sig), _p(y), out_dtype, B, T, C, rate, key, _s()), 'add_timing_dropout')
     return y
 
 
 def dropout_bwd(dy, rate, key, out=None):
     dx = torch.empty_like(dy) if out is None else out
-    _chk(L().neurst_dropout_bwd(_p(_c(dy)), _p(dx), dy.numel(), dt_of(dy), rate, key, _s()), 'dropout_bwd')
+    _chk(_C.neurst_dropout_bwd(_p(_c(dy)), _p(dx), dy.numel(), dt_of(dy), rate, key, _s()), 'dropout_bwd')
     return dx
 
 
 def add_inplace(dst, src):
     assert dst.dtype == src.dtype and dst.numel() == src.numel()
-    _chk(L().neurst_add_inplace(_p(_c(dst)), _p(_c(src)), dst.numel(), dt_of(dst), _s()), 'add_inplace')
+    _chk(_C.neurst_add_inplace(_p(_c(dst)), _p(_c(src)), dst.numel(), dt_of(dst), _s()), 'add_inplace')
     return dst
 
 
 # ---- GEMM ----------------------------------------------------------------------------
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias=None, relu=False, relu_src=None, accumulate=False, split_k=1):
     assert A.dtype == B.dtype
-    _chk(L().neurst_gemm_bias_act(_p(A), _p(B), _p(C), _p(bias), _p(relu_src), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b),
-                                  dt_of(A), dt_of(C), int(relu), int(accumulate), split_k, _s()), 'gemm_bias_act')
+    rc = _C.neurst_gemm_bias_act(A.data_ptr(), B.data_ptr(), C.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                 0 if relu_src is None else relu_src.data_ptr(), M, N, K, lda, ldb, ldc, trans_a, trans_b,
+                                 _DT[A.dtype], _DT[C.dtype], relu, accumulate, split_k, _override_raw or _raw_stream(_cur_dev()))
+    if rc:
+        _lib.check(rc, 'gemm_bias_act')
     return C
 
 
@@ -182,13 +199,15 @@ def gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, split_k=1, bias_grad=Fals
 
 def gemm_wgrad_bias(A, B, C, opsum, sum_operand, M, N, K, lda, ldb, ldc, split_k=1):
     """C[M,N] += A^T.B (A [K,M], B [K,N]) and opsum += column sums of A (sum_operand 1) or B (2)."""
-    _chk(L().neurst_gemm_wgrad_bias(_p(A), _p(B), _p(C), _p(opsum), sum_operand, M, N, K, lda, ldb, ldc, dt_of(A), split_k, _s()),
-         'gemm_wgrad_bias')
+    rc = _C.neurst_gemm_wgrad_bias(A.data_ptr(), B.data_ptr(), C.data_ptr(), opsum.data_ptr(), sum_operand, M, N, K, lda, ldb, ldc,
+                                   _DT[A.dtype], split_k, _override_raw or _raw_stream(_cur_dev()))
+    if rc:
+        _lib.check(rc, 'gemm_wgrad_bias')
 
 
 def colsum(x2d, out, accumulate=True):
     M, N = x2d.shape
-    _chk(L().neurst_colsum(_p(x2d), _p(out), M, N, x2d.stride(0), dt_of(x2d), int(accumulate), _s()), 'colsum')
+    _chk(_C.neurst_colsum(_p(x2d), _p(out), M, N, x2d.stride(0), dt_of(x2d), int(accumulate), _s()), 'colsum')
     return out
 
 
@@ -208,18 +227,18 @@ def mha_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, ke
     o = torch.empty((B, Tq, H * dh), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
     if keep_bits:
-        kb = torch.empty(L().neurst_mha_keep_bits_bytes(B, H, Tq, Tk) // 2, dtype=torch.int16, device=q.device) if rate > 0 else None
-        _chk(L().neurst_mha_fwd_train(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(kb), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode,
+        kb = torch.empty(_C.neurst_mha_keep_bits_bytes(B, H, Tq, Tk) // 2, dtype=torch.int16, device=q.device) if rate > 0 else None
+        _chk(_C.neurst_mha_fwd_train(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(kb), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode,
                                       _p(len_k), rate, key, dt_of(q), _s()), 'mha_fwd_train')
         return o, lse, kb
-    _chk(L().neurst_mha_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key,
+    _chk(_C.neurst_mha_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key,
                             dt_of(q), _s()), 'mha_fwd')
     return o, lse
 
 
 def mha_bwd(q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, keep_bits=None):
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
-    _chk(L().neurst_mha_bwd_train(_p(q), _p(k), _p(v), _p(o), _p(_c(d_o)), _p(lse), _p(keep_bits), _p(delta), _p(dq), _p(dk), _p(dv), ldq, ldk,
+    _chk(_C.neurst_mha_bwd_train(_p(q), _p(k), _p(v), _p(o), _p(_c(d_o)), _p(lse), _p(keep_bits), _p(delta), _p(dq), _p(dk), _p(dv), ldq, ldk,
                                   ldv, H * dh, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key, dt_of(q), _s()), 'mha_bwd')
 
 
@@ -230,7 +249,7 @@ def dropout_add_layernorm_fwd(x, y_inout, gamma, beta, rate, key, lens=None, T=0
     out = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _chk(L().neurst_dropout_add_layernorm_fwd(_p(_c(x)), _p(_c(y_inout)), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, C, rate, key,
+    _chk(_C.neurst_dropout_add_layernorm_fwd(_p(_c(x)), _p(_c(y_inout)), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, C, rate, key,
                                               _p(lens), T, dt_of(x), _s()), 'dropout_add_layernorm_fwd')
     return out, mean, rstd
 
@@ -244,16 +263,16 @@ def dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dgamma, dbeta, rate, k
     dy = torch.empty_like(z) if rate > 0 else dz
     partial = None
     if deterministic:
-        nblk = L().neurst_layernorm_bwd_blocks(rows)
+        nblk = _C.neurst_layernorm_bwd_blocks(rows)
         partial = torch.empty(2 * nblk * C, dtype=torch.float32, device=z.device)
-    _chk(L().neurst_dropout_add_layernorm_bwd(_p(_c(dout)), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dy), _p(dgamma), _p(dbeta),
+    _chk(_C.neurst_dropout_add_layernorm_bwd(_p(_c(dout)), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dy), _p(dgamma), _p(dbeta),
                                               _p(partial), rows, C, rate, key, _p(lens), T, dt_of(z), _s()), 'dropout_add_layernorm_bwd')
     return dz, dy
 
 
 def mask_rows_(x, lens):
     B, T, C = x.shape
-    _chk(L().neurst_mask_rows(_p(_c(x)), _p(lens), B, T, C, dt_of(x), _s()), 'mask_rows')
+    _chk(_C.neurst_mask_rows(_p(_c(x)), _p(lens), B, T, C, dt_of(x), _s()), 'mask_rows')
     return x
 
 
@@ -261,7 +280,7 @@ def mask_rows_(x, lens):
 def build_decoder_input(labels, len_labels, sos):
     B, Ln = labels.shape
     inp = torch.empty_like(labels)
-    _chk(L().neurst_build_decoder_input(_p(_c(labels)), _p(len_labels), _p(inp), B, Ln, sos, _s()), 'build_decoder_input')
+    _chk(_C.neurst_build_decoder_input(_p(_c(labels)), _p(len_labels), _p(inp), B, Ln, sos, _s()), 'build_decoder_input')
     return inp
 
 
@@ -271,14 +290,14 @@ def embedding_fwd(ids, table, out_dtype, rate, key, pos0=0, signal_len=None):
     sig = timing_signal_table(signal_len or (pos0 + Ln), D, ids.device)
     out = torch.empty((B, Ln, D), dtype=torch_dtype(out_dtype), device=ids.device)
     sig_ptr = sig.data_ptr() + pos0 * D * 4
-    _chk(L().neurst_embedding_fwd(_p(_c(ids)), _p(table), sig_ptr, _p(out), B, Ln, D, V, rate, key, out_dtype, _s()), 'embedding_fwd')
+    _chk(_C.neurst_embedding_fwd(_p(_c(ids)), _p(table), sig_ptr, _p(out), B, Ln, D, V, rate, key, out_dtype, _s()), 'embedding_fwd')
     return out
 
 
 def embedding_bwd(ids, dout, dtable, rate, key):
     B, Ln = ids.shape
     V, D = dtable.shape
-    _chk(L().neurst_embedding_bwd(_p(ids), _p(_c(dout)), _p(dtable), B, Ln, D, V, rate, key, dt_of(dout), _s()), 'embedding_bwd')
+    _chk(_C.neurst_embedding_bwd(_p(ids), _p(_c(dout)), _p(dtable), B, Ln, D, V, rate, key, dt_of(dout), _s()), 'embedding_bwd')
 
 
 # ---- CTC / greedy / shrink -------------------------------------------------------------------
@@ -290,17 +309,17 @@ def ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, grad_dtype, grad_sc
     loss = torch.empty(B, dtype=torch.float32, device=logits.device)
     grad = logits if (in_place and grad_dtype == F32) else torch.empty((B, T, V), dtype=torch_dtype(grad_dtype), device=logits.device)
     argmax = torch.empty((B, T), dtype=torch.int32, device=logits.device)
-    ws = torch.empty(L().neurst_ctc_workspace_bytes(B, T, Umax), dtype=torch.uint8, device=logits.device)
+    ws = torch.empty(_C.neurst_ctc_workspace_bytes(B, T, Umax), dtype=torch.uint8, device=logits.device)
     labels = _c(labels)
     args = (_p(_c(logits)), _p(len_logits), _p(labels), _p(len_labels), _p(loss), _p(grad), grad_dtype, _p(argmax), _p(ws), B, T, V, Umax,
             grad_scale)
     if recursion_stream is None:
-        _chk(L().neurst_ctc_loss_fwd_bwd_phased(*args, 3, _s()), 'ctc_loss_fwd_bwd')
+        _chk(_C.neurst_ctc_loss_fwd_bwd_phased(*args, 3, _s()), 'ctc_loss_fwd_bwd')
         return loss, grad, argmax
-    _chk(L().neurst_ctc_loss_fwd_bwd_phased(*args, 1, _s()), 'ctc_loss_fwd_bwd(frames)')
+    _chk(_C.neurst_ctc_loss_fwd_bwd_phased(*args, 1, _s()), 'ctc_loss_fwd_bwd(frames)')
     recursion_stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(recursion_stream):
-        _chk(L().neurst_ctc_loss_fwd_bwd_phased(*args, 2, _s()), 'ctc_loss_fwd_bwd(recursion)')
+        _chk(_C.neurst_ctc_loss_fwd_bwd_phased(*args, 2, _s()), 'ctc_loss_fwd_bwd(recursion)')
     for t in (ws, loss, grad, labels, len_logits, len_labels):   # allocated on the current stream, still in use on the other one
         t.record_stream(recursion_stream)
     return loss, grad, argmax
@@ -309,7 +328,7 @@ def ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, grad_dtype, grad_sc
 def argmax_rows(logits2d):
     rows, V = logits2d.shape
     out = torch.empty(rows, dtype=torch.int32, device=logits2d.device)
-    _chk(L().neurst_argmax_rows(_p(_c(logits2d)), _p(out), rows, V, _s()), 'argmax_rows')
+    _chk(_C.neurst_argmax_rows(_p(_c(logits2d)), _p(out), rows, V, _s()), 'argmax_rows')
     return out
 
 
@@ -317,7 +336,7 @@ def ctc_greedy(argmax, len_logits, blank):
     B, T = argmax.shape
     out = torch.empty((B, T), dtype=torch.int32, device=argmax.device)
     out_len = torch.empty(B, dtype=torch.int32, device=argmax.device)
-    _chk(L().neurst_ctc_greedy(_p(_c(argmax)), _p(len_logits), _p(out), _p(out_len), B, T, blank, _s()), 'ctc_greedy')
+    _chk(_C.neurst_ctc_greedy(_p(_c(argmax)), _p(len_logits), _p(out), _p(out_len), B, T, blank, _s()), 'ctc_greedy')
     return out, out_len
 
 
@@ -325,21 +344,21 @@ def shrink_index(argmax, lens, blank):
     B, T = argmax.shape
     index = torch.empty((B, T), dtype=torch.int32, device=argmax.device)
     new_len = torch.empty(B, dtype=torch.int32, device=argmax.device)
-    _chk(L().neurst_shrink_index(_p(_c(argmax)), _p(lens), _p(index), _p(new_len), B, T, blank, _s()), 'shrink_index')
+    _chk(_C.neurst_shrink_index(_p(_c(argmax)), _p(lens), _p(index), _p(new_len), B, T, blank, _s()), 'shrink_index')
     return index, new_len
 
 
 def shrink_fwd(x, index, Tout):
     B, T, D = x.shape
     out = torch.empty((B, Tout, D), dtype=x.dtype, device=x.device)
-    _chk(L().neurst_shrink_fwd(_p(_c(x)), _p(index), _p(out), B, T, Tout, D, dt_of(x), _s()), 'shrink_fwd')
+    _chk(_C.neurst_shrink_fwd(_p(_c(x)), _p(index), _p(out), B, T, Tout, D, dt_of(x), _s()), 'shrink_fwd')
     return out
 
 
 def shrink_bwd(dout, index, T):
     B, Tout, D = dout.shape
     dx = torch.empty((B, T, D), dtype=dout.dtype, device=dout.device)
-    _chk(L().neurst_shrink_bwd(_p(_c(dout)), _p(index), _p(dx), B, T, Tout, D, dt_of(dout), _s()), 'shrink_bwd')
+    _chk(_C.neurst_shrink_bwd(_p(_c(dout)), _p(index), _p(dx), B, T, Tout, D, dt_of(dout), _s()), 'shrink_bwd')
     return dx
 
 
@@ -348,23 +367,23 @@ def ls_xent_fwd_bwd(logits, labels, len_labels, confidence, grad_dtype, grad_sca
     B, Ln, V = logits.shape
     xent = torch.empty((B, Ln), dtype=torch.float32, device=logits.device)
     grad = logits if (in_place and grad_dtype == F32) else torch.empty((B, Ln, V), dtype=torch_dtype(grad_dtype), device=logits.device)
-    _chk(L().neurst_ls_xent_fwd_bwd(_p(_c(logits)), _p(_c(labels)), _p(len_labels), _p(xent), _p(grad), grad_dtype, B, Ln, V, confidence,
+    _chk(_C.neurst_ls_xent_fwd_bwd(_p(_c(logits)), _p(_c(labels)), _p(len_labels), _p(xent), _p(grad), grad_dtype, B, Ln, V, confidence,
                                     grad_scale, _s()), 'ls_xent_fwd_bwd')
     return xent, grad
 
 
 def mse_fwd_bwd(pred, label, grad_scale):
     n = pred.numel()
-    nblk = L().neurst_mse_blocks(n)
+    nblk = _C.neurst_mse_blocks(n)
     partial = torch.empty(nblk, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred)
-    _chk(L().neurst_mse_fwd_bwd(_p(_c(pred)), _p(_c(label)), dt_of(label), _p(partial), _p(dpred), n, grad_scale, dt_of(pred), _s()), 'mse_fwd_bwd')
+    _chk(_C.neurst_mse_fwd_bwd(_p(_c(pred)), _p(_c(label)), dt_of(label), _p(partial), _p(dpred), n, grad_scale, dt_of(pred), _s()), 'mse_fwd_bwd')
     return partial, dpred
 
 
 def loss_combine(xent, ctc, mse_partial, mse_numel, B, Ln, w_ast, w_ctc, w_kd, device):
     out = torch.empty(4, dtype=torch.float32, device=device)
-    _chk(L().neurst_loss_combine(_p(xent), _p(ctc), _p(mse_partial), 0 if mse_partial is None else mse_partial.numel(), mse_numel, B, Ln,
+    _chk(_C.neurst_loss_combine(_p(xent), _p(ctc), _p(mse_partial), 0 if mse_partial is None else mse_partial.numel(), mse_numel, B, Ln,
                                  w_ast, w_ctc, w_kd, _p(out), _s()), 'loss_combine')
     return out
 
@@ -382,7 +401,7 @@ def conv2d_ln_relu_fwd(x, w, bias, gamma, beta, kernel, stride):
     out = torch.empty_like(conv_out)
     mean = torch.empty(B * Ho * Wo, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _chk(L().neurst_conv2d_ln_relu_fwd(_p(_c(x)), _p(w), _p(bias), _p(gamma), _p(beta), _p(conv_out), _p(out), _p(mean), _p(rstd), B, H, W, Cin,
+    _chk(_C.neurst_conv2d_ln_relu_fwd(_p(_c(x)), _p(w), _p(bias), _p(gamma), _p(beta), _p(conv_out), _p(out), _p(mean), _p(rstd), B, H, W, Cin,
                                        Cout, kernel[0], kernel[1], stride[0], stride[1], dt_of(x), _s()), 'conv2d_ln_relu_fwd')
     return out, conv_out, mean, rstd
 
@@ -392,7 +411,7 @@ def conv2d_ln_relu_bwd(dout, x, w, gamma, conv_out, out, mean, rstd, dw, dbias, 
     Cout = w.shape[-1]
     ws = torch.empty_like(conv_out)
     dx = torch.empty_like(x) if need_dx else None
-    _chk(L().neurst_conv2d_ln_relu_bwd(_p(_c(dout)), _p(x), _p(w), _p(gamma), _p(conv_out), _p(out), _p(mean), _p(rstd), _p(ws), _p(dx), _p(dw),
+    _chk(_C.neurst_conv2d_ln_relu_bwd(_p(_c(dout)), _p(x), _p(w), _p(gamma), _p(conv_out), _p(out), _p(mean), _p(rstd), _p(ws), _p(dx), _p(dw),
                                        _p(dbias), _p(dgamma), _p(dbeta), B, H, W, Cin, Cout, kernel[0], kernel[1], stride[0], stride[1],
                                        dt_of(x), _s()), 'conv2d_ln_relu_bwd')
     return dx
@@ -402,49 +421,49 @@ def maxpool3x3_fwd(x):
     B, H, W, C = x.shape
     out = torch.empty_like(x)
     arg = torch.empty((B, H, W, C), dtype=torch.int8, device=x.device)
-    _chk(L().neurst_maxpool3x3_fwd(_p(_c(x)), _p(out), _p(arg), B, H, W, C, dt_of(x), _s()), 'maxpool3x3_fwd')
+    _chk(_C.neurst_maxpool3x3_fwd(_p(_c(x)), _p(out), _p(arg), B, H, W, C, dt_of(x), _s()), 'maxpool3x3_fwd')
     return out, arg
 
 
 def maxpool3x3_bwd(dout, arg):
     B, H, W, C = dout.shape
     dx = torch.empty_like(dout)
-    _chk(L().neurst_maxpool3x3_bwd(_p(_c(dout)), _p(arg), _p(dx), B, H, W, C, dt_of(dout), _s()), 'maxpool3x3_bwd')
+    _chk(_C.neurst_maxpool3x3_bwd(_p(_c(dout)), _p(arg), _p(dx), B, H, W, C, dt_of(dout), _s()), 'maxpool3x3_bwd')
     return dx
 
 
 # ---- optimiser / casts / greedy step ---------------------------------------------------------------------
 def adam_step(p, g, m, v, shadow, lr_t, beta1, beta2, eps, grad_scale):
-    _chk(L().neurst_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()), 'adam_step')
+    _chk(_C.neurst_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()), 'adam_step')
 
 
 def cast_f32_to_bf16(src, dst):
-    _chk(L().neurst_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _s()), 'cast_f32_to_bf16')
+    _chk(_C.neurst_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _s()), 'cast_f32_to_bf16')
 
 
 def cast_bf16_to_f32(src, dst):
-    _chk(L().neurst_cast_bf16_to_f32(_p(src), _p(dst), src.numel(), _s()), 'cast_bf16_to_f32')
+    _chk(_C.neurst_cast_bf16_to_f32(_p(src), _p(dst), src.numel(), _s()), 'cast_bf16_to_f32')
 
 
 def greedy_step(logits2d, preds, finished, len_decoded, n_unfinished, step, eos):
     B, V = logits2d.shape
-    _chk(L().neurst_greedy_step(_p(_c(logits2d)), _p(preds), _p(finished), _p(len_decoded), _p(n_unfinished), B, V, step, preds.shape[1], eos, _s()),
+    _chk(_C.neurst_greedy_step(_p(_c(logits2d)), _p(preds), _p(finished), _p(len_decoded), _p(n_unfinished), B, V, step, preds.shape[1], eos, _s()),
          'greedy_step')
 
 
 def selftest_mma(A, Bt):
     K = A.shape[1]
     C = torch.empty((16, 16), dtype=torch.float32, device=A.device)
-    _chk(L().neurst_selftest_mma(_p(_c(A)), _p(_c(Bt)), _p(C), K, dt_of(A), _s()), 'selftest_mma')
+    _chk(_C.neurst_selftest_mma(_p(_c(A)), _p(_c(Bt)), _p(C), K, dt_of(A), _s()), 'selftest_mma')
     return C
 
 
 def lens_ceil_div(lens, div):
     out = torch.empty_like(lens)
-    _chk(L().neurst_lens_ceil_div(_p(lens), _p(out), lens.numel(), div, _s()), 'lens_ceil_div')
+    _chk(_C.neurst_lens_ceil_div(_p(lens), _p(out), lens.numel(), div, _s()), 'lens_ceil_div')
     return out
 
 
 def mha_fwd_strided(q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode, len_k):
-    _chk(L().neurst_mha_fwd_strided(_p(q), _p(k), _p(v), _p(o), _p(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode,
+    _chk(_C.neurst_mha_fwd_strided(_p(q), _p(k), _p(v), _p(o), _p(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode,
                                     _p(len_k), 0.0, 0, dt_of(q), _s()), 'mha_fwd_strided')
