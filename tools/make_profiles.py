@@ -24,6 +24,8 @@ def gemm_label(name):
     mt = re.match(r'_Z16gemm_thin_kernelI(DF16b|f)Lb([01])EEv8GemmArgs', name)
     if mt:
         return 'gemm_thin_kernel<bf16,%s,%s>' % ('bf16' if mt.group(1) == 'DF16b' else 'f32', 'NT' if mt.group(2) == '1' else 'NN')
+    if name.startswith('void gemm_thin_kernel<bool _Accum, bool'):   # rocprofv3's half-demangled spelling of <bf16, true> (the NN one stays mangled)
+        return 'gemm_thin_kernel<bf16,bf16,NT>'
     m = re.match(r'_Z11gemm_kernelI(DF16b|f)(DF16b|f)Lb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)EEv8GemmArgs', name)
     if m:
         t, tc, ta, tbk, fast, sumop, ns = m.groups()
