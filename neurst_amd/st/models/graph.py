@@ -133,19 +133,25 @@ class Tape:
 
     def __init__(self):
         self.nodes = []
+        self.early = []             # nodes whose output gradient exists before backward starts (see push)
         self.grads = {}
         self.keep = {}
         self.relu_outputs = set()   # ids of tensors produced by a fused ReLU: their gradient is gated where it is produced
 
-    def push(self, fn):
-        self.nodes.append(fn)
+    def push(self, fn, early=False):
+        """early=True: the node's output gradient is set by the loss itself (the CTC head), so backward may run it first,
+        on the second stream, beside the latency-bound decoder backward instead of after it."""
+        (self.early if early else self.nodes).append(fn)
 
     def grad(self, t):
         return self.grads.get(id(t))
 
     def pop(self, t):
         self.keep.pop(id(t), None)
-        return self.grads.pop(id(t), None)
+        g = self.grads.pop(id(t), None)
+        if g is not None and _current and _current[-1].side_writes:
+            _current[-1].before_read(g)
+        return g
 
     def has(self, t):
         return id(t) in self.grads
@@ -163,9 +169,15 @@ class Tape:
             self.set(t, g)
 
     def backward(self):
+        g = _current[-1] if _current else None
+        for fn in self.early:
+            if g is not None and g.run_early(fn):
+                continue
+            fn()
         for fn in reversed(self.nodes):
             fn()
         self.nodes.clear()
+        self.early.clear()
 
 
 def side_wgrad_rows_from_env():
@@ -201,6 +213,8 @@ class Graph:
         self.side_reads = set()
         self.side_keep = []
         self.side_used = False
+        self.in_early = False
+        self.side_writes = set()
 
     @contextlib.contextmanager
     def variable_scope(self, name):
@@ -272,6 +286,43 @@ class Graph:
         self.side_keep.append(read_tensors)
         self.side_used = True
 
+    def run_early(self, fn):
+        """Run a whole backward node (weight AND data gradient) on the second stream, after everything enqueued so far.
+        Returns False when there is no second stream to use."""
+        if not self.side_streams or self.store.grads.device.type != 'cuda':
+            return False
+        if self.wgrad_stream is None:
+            self.wgrad_stream = torch.cuda.Stream(device=self.store.grads.device)
+        side = self.wgrad_stream
+        side.wait_stream(torch.cuda.current_stream())
+        self.in_early = True
+        try:
+            with torch.cuda.stream(side):
+                fn()
+        finally:
+            self.in_early = False
+        self.side_used = True
+        return True
+
+    def side_written(self, *tensors):
+        """Tensors produced on the second stream: the main stream waits for it before it updates one of them in place;
+        a plain READ on the main stream must be preceded by that wait too (callers: only gradients that are always
+        accumulated into before anything reads them)."""
+        for t in tensors:
+            p = t.untyped_storage().data_ptr()
+            self.side_reads.add(p)
+            self.side_writes.add(p)
+        self.side_keep.append(tensors)
+
+    def before_read(self, t):
+        """The main stream is about to read a gradient: wait if the second stream produced it (and nothing was accumulated
+        into it since, which would already have waited)."""
+        p = t.untyped_storage().data_ptr()
+        if p in self.side_writes:
+            self.side_writes.discard(p)
+            if p in self.side_reads:
+                self.before_inplace_write(t)
+
     def before_inplace_write(self, t):
         """Main-stream kernels are about to update `t` in place: if a side-stream kernel may still read that storage,
         wait for the side stream's tail (covers every reader enqueued so far)."""
@@ -287,6 +338,7 @@ class Graph:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self.side_used = False
         self.side_reads.clear()
+        self.side_writes.clear()
         self.side_keep.clear()
 
 

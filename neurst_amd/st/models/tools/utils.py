@@ -32,7 +32,7 @@ def _wgrad(dy2, x2, param, layout, bias=None):
             ops.gemm(x2, dy2, param.grad, n_in, n_out, M, n_in, n_out, n_out, True, False, accumulate=True, split_k=sk)
 
 
-def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient):
+def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient, early_backward=False):
     g = G.current()
     n_in = inputs.shape[-1]
     x2 = _flat2d(inputs)
@@ -75,7 +75,9 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient):
                     ops.gemm(dy2, w.w, dx, M, n_in, units, units, units, n_in, False, True, relu_src=gate, accumulate=have)
                 if not have:
                     tape.set(inputs, dx)
-        tape.push(bwd)
+                if g.in_early:
+                    g.side_written(dx)
+        tape.push(bwd, early=early_backward)
     return out
 
 
@@ -88,14 +90,14 @@ def dense(inputs, units, activation=None, use_bias=True, kernel=None, reuse=None
     return _linear(inputs, w, b, units, activation == 'relu', 'out_in', out_dtype, stop_gradient)
 
 
-def tf_layers_dense(inputs, units, use_bias=False, name=None, out_dtype=None, stop_gradient=False):
+def tf_layers_dense(inputs, units, use_bias=False, name=None, out_dtype=None, stop_gradient=False, early_backward=False):
     """tf.layers.dense(use_bias=False): x . kernel, kernel [in, units]
     (transformer_encoder.py:117-122, fc_decoder.py:33-38, transformer_decoder.py:42-46)."""
     assert not use_bias
     g = G.current()
     with g.variable_scope(name):
         w = g.get_variable('kernel', [inputs.shape[-1], units])
-    return _linear(inputs, w, None, units, False, 'in_out', out_dtype, stop_gradient)
+    return _linear(inputs, w, None, units, False, 'in_out', out_dtype, stop_gradient, early_backward)
 
 
 def ff_hidden(inputs, hidden_size, output_size, activation='relu', use_bias=True, reuse=None, name=None):
