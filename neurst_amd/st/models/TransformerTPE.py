@@ -147,6 +147,7 @@ class TransformerTPE(Seq2SeqModel):
         self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 32) * (1 << 20)) // 256 * 256, 256),
                                      producer_streams=lambda: (self.graph.wgrad_stream,))
         self.graph.on_param_grad = self.bucketer.param_done
+        self.graph.on_node_done = self.bucketer.node_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
         self._make_modules()
         self.__class__.num_Instances += 1

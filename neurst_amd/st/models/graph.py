@@ -170,12 +170,14 @@ class Tape:
 
     def backward(self):
         g = _current[-1] if _current else None
+        done = g.on_node_done if (g is not None and g.on_node_done is not None) else (lambda: None)
         for fn in self.early:
-            if g is not None and g.run_early(fn):
-                continue
-            fn()
+            if not (g is not None and g.run_early(fn)):
+                fn()
+            done()
         for fn in reversed(self.nodes):
             fn()
+            done()
         self.nodes.clear()
         self.early.clear()
 
@@ -202,6 +204,7 @@ class Graph:
         self.name_counts = {}
         self.dropout_enabled = True
         self.on_param_grad = None   # callback(Param) once a parameter's gradient kernels are enqueued
+        self.on_node_done = None    # callback() after every backward node (all its kernels are enqueued)
         # Weight gradients run on a second HIP stream beside the data-gradient chain: small layers cannot fill the chip on
         # their own, and for large ones each kernel's ramp-up and drain (~12 us per launch, measured) is covered by the
         # other stream's steady state.  side_wgrad_rows = (min, max) input rows of the layers that take part

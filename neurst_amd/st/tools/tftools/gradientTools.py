@@ -20,16 +20,21 @@ class GradBucketer:
     that writes it.  If `apply_fn(start, end)` is set (it enqueues the optimizer update of arena[start:end] on the
     current stream), a bucket is also UPDATED during backward, on that same side stream, behind its all-reduce: Adam is
     HBM-bound and hides under the matrix-core work of the remaining backward.  The update of a bucket is enqueued one
-    bucket late - when the NEXT bucket completes - because the data-gradient GEMM of the layer that completed it still
-    reads the weights and is enqueued right after the completion call."""
+    step late because the data-gradient GEMM of the layer that completed it still
+    reads the weights and is enqueued right after the completion call.  "Late" is counted in backward NODES: buckets
+    completed while a node (one layer's backward closure) runs are updated when `node_done()` is called after it, by which
+    time every kernel of that node - the data-gradient GEMM included - is in the stream the update waits for."""
 
     def __init__(self, store, bucket_bytes=32 << 20, group=None, comm_stream=None, producer_streams=None):
         self.store = store
         self.producer_streams = producer_streams or (lambda: ())   # other streams that may hold gradient kernels
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # the collectives run when there is more than one rank - or, for tests of the RCCL / stream plumbing on a one-GPU
+        # box, whenever a process group exists and NEURST_FORCE_BUCKETS is set (an all-reduce over one rank is the identity)
+        self.reduce = self.world > 1 or (bool(os.environ.get('NEURST_FORCE_BUCKETS')) and dist.is_available() and dist.is_initialized())
         self.use_stream = store.grads.is_cuda
-        self.comm_stream = comm_stream or (torch.cuda.Stream() if (self.use_stream and self.world > 1) else None)
+        self.comm_stream = comm_stream or (torch.cuda.Stream() if (self.use_stream and self.reduce) else None)
         self.apply_fn = None
         elems = max(bucket_bytes // 4, 1)
         # buckets follow arena order; a parameter belongs to the bucket of its first element
@@ -55,7 +60,7 @@ class GradBucketer:
         self.handles = [None] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
         self.applied = [False] * len(self.bounds)
-        self.waiting = None          # completed bucket whose update is still held back (see class docstring)
+        self.ready = []              # completed buckets whose update is held back until the running backward node is done
 
     def _side_stream(self):
         if self.use_stream and self.comm_stream is None:
@@ -64,13 +69,13 @@ class GradBucketer:
 
     def param_done(self, p):
         """Called by backward once every kernel writing p.grad has been enqueued."""
-        if self.world == 1 and self.apply_fn is None:
+        if not self.reduce and self.apply_fn is None:
             return
         first, last = self.param_bucket[p.name]
         if p.name in self.done_params:
             # a variable used by two layers: its first user already reported it.  Harmless while the bucket is untouched
             # (kernels run in stream order), an error once the bucket has been reduced or updated without this gradient.
-            if any(self.applied[b] or (self.launched[b] and self.world > 1) for b in range(first, last + 1)):
+            if any(self.applied[b] or (self.launched[b] and self.reduce) for b in range(first, last + 1)):
                 raise RuntimeError('gradient of shared variable {} produced after its bucket was reduced/updated'.format(p.name))
             return
         self.done_params.add(p.name)
@@ -80,12 +85,17 @@ class GradBucketer:
                 self._complete(b)
 
     def _complete(self, b):
-        if self.world > 1:
+        if self.reduce:
             self._launch(b)
         if self.apply_fn is not None:
-            if self.waiting is not None:
-                self._apply(self.waiting)
-            self.waiting = b
+            self.ready.append(b)
+
+    def node_done(self):
+        """Called by the tape after every backward node."""
+        if self.ready and self.apply_fn is not None:
+            for b in self.ready:
+                self._apply(b)
+            self.ready = []
 
     def _wait_for_producers(self, stream):
         ev = torch.cuda.Event()
@@ -132,9 +142,9 @@ class GradBucketer:
         """Launch whatever is left (parameters without gradient this step), wait for all buckets; with apply_fn set also
         update every bucket not updated yet.  Returns the 1/world of the mean (already used by apply_fn if that is set)."""
         scale = 1.0 / self.world
-        if self.world == 1 and self.apply_fn is None:
+        if not self.reduce and self.apply_fn is None:
             return scale
-        if self.world > 1:
+        if self.reduce:
             for b in range(len(self.bounds)):
                 self._launch(b)
         if self.apply_fn is not None:

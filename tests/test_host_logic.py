@@ -133,8 +133,8 @@ st.grads = torch.ones(st.total) * (rank + 1)
 for n in ['p0'] + order:
     b.param_done(st.vars[n])
 assert average_gradients(b) == 0.5 and torch.equal(st.grads, torch.ones(st.total) * 3)
-# third step: buckets are also UPDATED while "backward" runs - each exactly once, only after its all-reduce, and one
-# bucket late (the layer that completes a bucket still reads its weights right after reporting)
+# third step: buckets are also UPDATED while "backward" runs - each exactly once, only after its all-reduce, and only
+# after the node that completed them has ended (that layer still reads its weights right after reporting)
 st.grads = torch.ones(st.total) * (rank + 1)
 seen = []
 def apply_fn(s, e):
@@ -142,11 +142,14 @@ def apply_fn(s, e):
     seen.append((s, e))
 b.apply_fn = apply_fn
 during = []
-for n in order:
+for n in order:                                   # one "backward node" per variable: param_done, (its dgrad), node_done
+    before = len(seen)
     b.param_done(st.vars[n])
+    assert len(seen) == before, 'a bucket was updated inside the node that completed it'
+    b.node_done()
     during.append(len(seen))
 completed = sum(1 for x in b.pending if x == 0)
-assert during[-1] == completed - 1 and during[-1] >= 1, (during, completed)     # the newest completed bucket is held back
+assert during[-1] == completed and during[-1] >= 1, (during, completed)
 assert average_gradients(b) == 0.5
 assert sorted(seen) == list(b.bounds), seen                                     # every bucket once, p0's included
 b.apply_fn = None
@@ -155,6 +158,7 @@ b.apply_fn = lambda s, e: None
 b.param_done(st.vars['p5']); b.param_done(st.vars['p4']); b.param_done(st.vars['p4'])
 for n in ['p3', 'p1', 'p2']:
     b.param_done(st.vars[n])
+b.node_done()
 try:
     b.param_done(st.vars['p4'])
     raise SystemExit('late gradient of a shared variable was accepted')
