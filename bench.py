@@ -19,6 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import neurst_amd  # noqa: E402,F401  (first: asks HIP for 6 hardware queues before the runtime starts, neurst_amd/__init__.py)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -147,7 +148,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(0 if a.rehearse_one_gpu else local_rank)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ       # under torch.distributed.run also with one rank: same code path as N > 1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if a.rehearse_one_gpu:
@@ -180,7 +182,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -192,7 +194,7 @@ def main():
         out4 = model.train_step_async(batch)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -212,7 +214,7 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
         model.graph.side_streams = side_streams
-    if world > 1:
+    if use_dist:
         dist.barrier()
     losses = out4.cpu().numpy()
     assert np.isfinite(losses).all(), losses
@@ -253,7 +255,7 @@ def main():
             threads = min(os.cpu_count() or 1, 16)
             res['cpu_baseline'] = cpu_baseline(threads)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
