@@ -323,13 +323,18 @@ class TransformerTPE(Seq2SeqModel):
         return out4
 
     def _step(self, batch):
-        """forward + backward + gradient mean + Adam.  NEURST_OVERLAP_ADAM=1: the Adam update of a gradient bucket is
-        enqueued on a side stream as soon as backward has finished with the bucket (GradBucketer) instead of one launch
-        over the whole arena at the end.  Off by default: on one MI355X it measured 1.7 % SLOWER (LUT 17.05 vs 16.76
-        ms/step) - Adam streams 30 B per parameter and takes HBM bandwidth and memory-side cache from the GEMMs it
-        overlaps."""
-        overlap = (not self.frozen) and self.graph.side_streams and self.device.type == 'cuda' and \
-            os.environ.get('NEURST_OVERLAP_ADAM', '0') == '1'
+        """forward + backward + gradient mean + Adam.  NEURST_OVERLAP_ADAM selects where the Adam kernel runs:
+        `off`  (default) one launch over the whole arena after the gradient mean;
+        `tail` per bucket, after backward, in the order the all-reduces were launched and on the communication stream -
+               early buckets are updated while later ones are still in flight;
+        `backward` per bucket as soon as backward has finished with it (GradBucketer).
+        Measured on one MI355X with the bucket path forced on over RCCL (one rank, so no real traffic to hide behind):
+        off 16.65, backward 16.67, tail 16.99 ms/step - 18 small Adam launches cost more than one large one, so the
+        overlapped modes stay opt-in until a multi-GPU measurement says otherwise."""
+        mode = os.environ.get('NEURST_OVERLAP_ADAM') or 'off'
+        mode = {'0': 'off', '1': 'backward'}.get(mode, mode)
+        overlap = mode in ('tail', 'backward') and (not self.frozen) and self.graph.side_streams and self.device.type == 'cuda'
+        self.bucketer.apply_in_backward = mode == 'backward'
         if overlap:
             lr, self.bucketer.apply_fn = self.optimizer_update_fn(self.store, 1.0 / self.bucketer.world)
         try:

@@ -36,6 +36,7 @@ class GradBucketer:
         self.use_stream = store.grads.is_cuda
         self.comm_stream = comm_stream or (torch.cuda.Stream() if (self.use_stream and self.reduce) else None)
         self.apply_fn = None
+        self.apply_in_backward = True    # False: buckets are only updated in finish(), in launch order, behind their all-reduce
         elems = max(bucket_bytes // 4, 1)
         # buckets follow arena order; a parameter belongs to the bucket of its first element
         self.bounds = []
@@ -60,6 +61,7 @@ class GradBucketer:
         self.handles = [None] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
         self.applied = [False] * len(self.bounds)
+        self.order = []              # buckets in the order their all-reduce was launched
         self.ready = []              # completed buckets whose update is held back until the running backward node is done
 
     def _side_stream(self):
@@ -87,7 +89,7 @@ class GradBucketer:
     def _complete(self, b):
         if self.reduce:
             self._launch(b)
-        if self.apply_fn is not None:
+        if self.apply_fn is not None and self.apply_in_backward:
             self.ready.append(b)
 
     def node_done(self):
@@ -109,6 +111,7 @@ class GradBucketer:
         if self.launched[b]:
             return
         self.launched[b] = True
+        self.order.append(b)
         if _DEBUG:
             print('[bucketer r%d] launch bucket %d of %d' % (dist.get_rank(), b, len(self.bounds)), flush=True)
         s, e = self.bounds[b]
@@ -148,7 +151,8 @@ class GradBucketer:
             for b in range(len(self.bounds)):
                 self._launch(b)
         if self.apply_fn is not None:
-            for b in reversed(range(len(self.bounds))):
+            # in launch order: the update of an early bucket runs while the all-reduces of the later ones are still in flight
+            for b in self.order + [b for b in reversed(range(len(self.bounds))) if b not in self.order]:
                 self._apply(b)
         else:
             for i, h in enumerate(self.handles):

@@ -257,8 +257,8 @@ os.environ['NEURST_FORCE_BUCKETS'] = '1'
 dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%%s' %% sys.argv[1], rank=0, world_size=1, device_id=torch.device('cuda', 0))
 batch = make_batch(B=3, Traw=40, V=11, L=6, U=3, Lb=5, bert_dim=16, dim_raw=4, ragged=True, seed=1)
 results = {}
-for mode in ('plain', 'buckets', 'buckets+adam'):
-    os.environ['NEURST_OVERLAP_ADAM'] = '1' if mode == 'buckets+adam' else '0'
+for mode in ('plain', 'buckets', 'buckets+adam', 'buckets+tail'):
+    os.environ['NEURST_OVERLAP_ADAM'] = {'buckets+adam': 'backward', 'buckets+tail': 'tail'}.get(mode, 'off')
     args = ge.tiny_args(compute_dtype='fp32')
     args.grad_bucket_mb = 0.004
     model = args.Model(GlobalStep(0), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
@@ -272,7 +272,7 @@ for mode in ('plain', 'buckets', 'buckets+adam'):
     losses += [model.train_step(batch)[0] for _ in range(2)]
     torch.cuda.synchronize()
     results[mode] = (losses, g1, p1)
-for mode in ('buckets', 'buckets+adam'):
+for mode in ('buckets', 'buckets+adam', 'buckets+tail'):
     # the LN column sums are fp32 atomics (order varies run to run) and Adam divides by sqrt(v) + 1e-9, so parameters whose
     # gradient is rounding noise may move differently: compare the gradients, the well-conditioned parameters and the losses
     assert np.allclose(results[mode][0], results['plain'][0], rtol=1e-5), (mode, results[mode][0], results['plain'][0])
@@ -291,6 +291,7 @@ for mode in ('plain', 'buckets'):
     args = build_args(cfg, dim_output=1000, compute_dtype='bf16')
     model = args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
     model.bucketer.reduce = mode == 'buckets'
+    os.environ.pop('NEURST_OVERLAP_ADAM', None)      # default: one Adam launch after the gradient mean
     b2 = make_batch(B=8, Traw=600, V=1000, L=12, U=10, Lb=9, bert_dim=768, ragged=True, seed=4)
     wide[mode] = [model.train_step(b2)[0] for _ in range(4)]
 assert np.allclose(wide['buckets'], wide['plain'], rtol=2e-3), wide
