@@ -134,6 +134,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--ragged', action='store_true')
+    ap.add_argument('--bucket-mb', type=float, default=None, help='size of the gradient buckets that are all-reduced as units (default: the config value or 64)')
     ap.add_argument('--serial-streams', action='store_true',
                     help='no second HIP streams (CTC recursion, weight gradients): every kernel has the chip to itself, as in '
                          'the per-kernel timing pass; used for the rocprofv3 runs whose durations profiles/ holds')
@@ -169,6 +170,8 @@ def main():
 
     V, Ln = 10000, 40
     args = build_args(a.config, dim_output=V, compute_dtype=a.dtype)
+    if a.bucket_mb:
+        args.grad_bucket_mb = a.bucket_mb
     is_lut = args.model.loss_type == 'ctc_kd_ce'
     if not is_lut:
         Ln = 80

@@ -144,7 +144,7 @@ class TransformerTPE(Seq2SeqModel):
         handle_gradients(self.args)
         if self.args.use_horovod:
             raise NotImplementedError('use_horovod: data parallelism is one process per GPU over RCCL (torch.distributed)')
-        self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 32) * (1 << 20)) // 256 * 256, 256),
+        self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 64) * (1 << 20)) // 256 * 256, 256),
                                      producer_streams=lambda: (self.graph.wgrad_stream,))
         self.graph.on_param_grad = self.bucketer.param_done
         self.graph.on_node_done = self.bucketer.node_done
