@@ -73,6 +73,29 @@ def test_fp32_losses_logits_grads_match_oracle(case):
     assert np.array_equal(model.last['len_encoded'].cpu().numpy(), ref['len_enc'])
 
 
+@pytest.mark.parametrize('case,B,Traw,L,U,Lb', [('lut', 1, 3, 1, 1, 1), ('lut', 2, 1, 2, 1, 2), ('costt', 1, 2, 1, 1, 1), ('costt', 2, 7, 3, 5, 1)])
+def test_fp32_degenerate_shapes_match_oracle(case, B, Traw, L, U, Lb):
+    """smallest shapes: one utterance, one encoder frame, one label; CTC rows whose label is longer than the input
+    (U = 5 on T = 3: infeasible, zeroed like `ignore_longer_outputs_than_inputs`), shrink with nothing kept"""
+    args = ge.tiny_args(compute_dtype='fp32', **CASES[case])
+    model = make_model(args)
+    P = perturb(model, seed=B + Traw)
+    batch = make_batch(B=B, Traw=Traw, V=11, L=L, U=U, Lb=Lb, bert_dim=16, dim_raw=4, ragged=False, seed=3)
+    out4 = model.forward_backward(batch).cpu().numpy()
+    cfg = ge.oracle_cfg_from_args(args).zero_dropout()
+    ref = OracleTPE(cfg, is_train=True, dropout=False).loss_and_grads({k: v.astype(np.float64) for k, v in P.items()}, oracle_batch(batch))
+    assert np.isfinite(out4).all()
+    assert abs(out4[0] - ref['loss']) < 1e-5 * max(abs(ref['loss']), 1e-3), (out4, ref['loss'])
+    assert abs(out4[2] - ref['loss_ctc']) < 1e-5 * max(abs(ref['loss_ctc']), 1e-3)
+    # with one key the attention weights are exactly 1, so the query / key projections have an exactly zero gradient:
+    # those tensors are compared on an absolute floor (1e-3, far below a typical gradient entry) instead of their own maximum
+    g = model.store.export_grads()
+    for k, v in ref['grads'].items():
+        err = np.abs(g[k] - v).max() / max(np.abs(v).max(), 1e-3)
+        assert err < 5e-5, (k, err)
+    assert np.array_equal(model.last['len_encoded'].cpu().numpy(), ref['len_enc'])
+
+
 def test_fp32_cnn_frontend_matches_oracle():
     args = ge.tiny_args(compute_dtype='fp32', loss_type='ce_ctc', use_cnn_resample=True, cnn={'layers': 2, 'kernel': '3,3', 'stride': '2,2'},
                         num_filters=4)
