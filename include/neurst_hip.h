@@ -253,6 +253,30 @@ int neurst_greedy_step(const float* logits, int32_t* preds, int32_t* finished, i
                        int32_t* n_unfinished, int64_t B, int64_t V, int64_t step, int64_t max_steps,
                        int32_t eos, void* stream);
 
+/* Beam search bookkeeping of Transformer_Decoder.beam_decode_rerank
+ * (st/models/decoders/transformer_decoder.py:248-431), one decoding step without a read-back.
+ * neurst_beam_topk (:303-341): scores[r, 0:k] / ids[r, 0:k] = the k largest entries of log_softmax(logits[r, :]) in
+ *   descending order, equal values by lower index (tf.nn.top_k); logits [rows, V] fp32, 1 <= k <= 16.
+ * neurst_beam_prune (:316-373): for each utterance b with `beam` live hypotheses (rows b*beam .. b*beam+beam-1):
+ *   a finished hypothesis keeps one branch that emits `eos` with branch score 0, its other branches get -1e10 (the
+ *   reference's finite `inf`, :14); candidate score = (scores[j] + branch score) / ((5 + len) / 6)^length_penalty_weight
+ *   with len = len_decoded[j] + (token != eos); the `beam` best of the beam^2 candidates (ties by lower candidate index)
+ *   give new_scores / new_len / new_tokens / parents (row index of the hypothesis they extend) / new_finished
+ *   (= finished[slot] | token == eos: the reference or-s the flags by slot without gathering them by parent, :368-369);
+ *   *n_unfinished += number of unfinished survivors.  prev_unfinished (may be NULL): the counter the previous step
+ *   wrote; when it is 0 the reference's while_loop (:375-383) has already ended, and a step the host enqueued before
+ *   reading that back copies the state through unchanged (parents = identity, tokens = eos).  1 <= beam <= 8; outputs
+ *   must not alias inputs.
+ * neurst_gather_rows (:361-362): dst[r] = src[idx[r]] for rows of row_bytes bytes at the given byte strides (predictions,
+ *   caches re-ordered by parent); rows < 65536; not in place. */
+int neurst_beam_topk(const float* logits, float* scores, int32_t* ids, int64_t rows, int64_t V, int k, void* stream);
+int neurst_beam_prune(const float* next_scores, const int32_t* next_ids, const float* scores, const int32_t* len_decoded,
+                      const int32_t* finished, float* new_scores, int32_t* new_len, int32_t* new_finished,
+                      int32_t* new_tokens, int32_t* parents, int32_t* n_unfinished, const int32_t* prev_unfinished,
+                      int64_t batch, int beam, int32_t eos, float length_penalty_weight, void* stream);
+int neurst_gather_rows(const void* src, void* dst, const int32_t* idx, int64_t rows, int64_t row_bytes, int64_t src_stride,
+                       int64_t dst_stride, void* stream);
+
 /* kernel self-test: one 16x16xK MFMA tile product through the same fragment loaders the
  * GEMM / attention kernels use (A [16,K], B^T [16,K] -> C [16,16] fp32). */
 int neurst_selftest_mma(const void* A, const void* Bt, float* C, int64_t K, int dtype, void* stream);

@@ -467,3 +467,35 @@ def lens_ceil_div(lens, div):
 def mha_fwd_strided(q, k, v, o, lse, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode, len_k):
     _chk(_C.neurst_mha_fwd_strided(_p(q), _p(k), _p(v), _p(o), _p(lse), ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode,
                                     _p(len_k), 0.0, 0, dt_of(q), _s()), 'mha_fwd_strided')
+
+
+# ---- beam search bookkeeping (transformer_decoder.py:248-431) ---------------------------------------------------
+def beam_topk(logits2d, k):
+    R, V = logits2d.shape
+    scores = torch.empty((R, k), dtype=torch.float32, device=logits2d.device)
+    ids = torch.empty((R, k), dtype=torch.int32, device=logits2d.device)
+    _chk(_C.neurst_beam_topk(_p(_c(logits2d)), _p(scores), _p(ids), R, V, k, _s()), 'beam_topk')
+    return scores, ids
+
+
+def beam_prune(next_scores, next_ids, scores, len_decoded, finished, n_unfinished, beam, eos, length_penalty_weight,
+               prev_unfinished=None):
+    R = scores.numel()
+    new_scores, new_len, new_fin = torch.empty_like(scores), torch.empty_like(len_decoded), torch.empty_like(finished)
+    tokens = torch.empty(R, dtype=torch.int32, device=scores.device)
+    parents = torch.empty(R, dtype=torch.int32, device=scores.device)
+    _chk(_C.neurst_beam_prune(_p(_c(next_scores)), _p(_c(next_ids)), _p(scores), _p(len_decoded), _p(finished), _p(new_scores), _p(new_len),
+                              _p(new_fin), _p(tokens), _p(parents), _p(n_unfinished), _p(prev_unfinished) if prev_unfinished is not None else None,
+                              R // beam, beam, eos, float(length_penalty_weight),
+                              _s()), 'beam_prune')
+    return new_scores, new_len, new_fin, tokens, parents
+
+
+def gather_rows(src, idx, out=None, row_bytes=None):
+    """out[r] = src[idx[r]] along dim 0 (src contiguous); row_bytes: only that many leading bytes of every row."""
+    src = _c(src)
+    out = torch.empty_like(src) if out is None else out
+    stride = src[0].numel() * src.element_size()
+    _chk(_C.neurst_gather_rows(_p(src), _p(out), _p(idx), idx.numel(), stride if row_bytes is None else row_bytes, stride, stride, _s()),
+         'gather_rows')
+    return out

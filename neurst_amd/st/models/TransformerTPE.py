@@ -365,8 +365,9 @@ class TransformerTPE(Seq2SeqModel):
     def infer(self, features, len_feas):
         """-> (preds [B, steps] int32 numpy, preds_am [B, T] int32 numpy zero padded)."""
         a = self.args
-        if (a.dirs and a.dirs.lm_checkpoint) or (a.beam_size or 1) > 1:
-            raise NotImplementedError('beam search / LM rerank (beam_size > 1) is outside the hot path; set beam_size: 1')
+        if a.dirs and a.dirs.lm_checkpoint:
+            raise NotImplementedError('LM rerank (dirs.lm_checkpoint) is outside the hot path')
+        beam = (a.beam_size or 1) > 1
         g = self.graph
         batch = self._to_device({'feature': features, 'len_fea': len_feas})
         with G.use_graph(g), G.variable_scope(self.name):
@@ -377,7 +378,10 @@ class TransformerTPE(Seq2SeqModel):
             encoded, len_encoded, logits_am, _ = self._encode(feature, len_fea, False, 0.0, batch)
             self.last.update(encoded=encoded, len_encoded=len_encoded)
             with G.variable_scope(self.decoder.name or 'decoder'):
-                _, preds, len_decoded = self.decoder.decoder_with_caching(encoded, len_encoded)
+                if beam:      # TransformerTPE.py:314-319
+                    self.last['beams'], preds, len_decoded = self.decoder.beam_decode_rerank(encoded, len_encoded)
+                else:
+                    _, preds, len_decoded = self.decoder.decoder_with_caching(encoded, len_encoded)
         self.last['len_decoded'] = len_decoded
         preds_am = self.last['preds_am'].cpu().numpy()
         maxlen = max(int(self.last['len_preds_am'].cpu().numpy().max()), 0)

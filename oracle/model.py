@@ -462,6 +462,39 @@ class OracleTPE:
                 'len_enc': len_enc, 'preds_am': st['preds_am'], 'grads': G}
 
     # ---- greedy inference (transformer_decoder.py:52-182, TransformerTPE.py:486-513)
+    def _cached_step(self, P, preds, cache, enc, len_enc):
+        """decoder_with_caching_impl + decoder_fc on the last position (transformer_decoder.py:123-182, :65-75):
+        re-embeds the whole prefix, runs every block on the last position only, caches block outputs."""
+        cfg = self.cfg
+        n = cfg.name
+        nb, d = cfg.dec_blocks, cfg.dec_units
+        emb = P[f'{n}/embedding'][preds]
+        x = emb + (emb + ops.timing_signal(preds.shape[1], emb.shape[-1], emb.dtype))
+        new_cache = []
+        for bi in range(nb):
+            p = f'{n}/decoder/block_{bi}'
+            pa = f'{p}/decoder_self_attention'
+            qkv = ops.dense_fwd(x, P[f'{pa}/qkv_transform/kernel'], P[f'{pa}/qkv_transform/bias'])
+            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+            a, _ = ops.mha_core_fwd(q[:, -1:], k, v, cfg.dec_heads, ops.MASK_NONE)
+            o = ops.dense_fwd(a, P[f'{pa}/output_transform/kernel'], P[f'{pa}/output_transform/bias'])
+            h, _ = ops.residual_fwd(x[:, -1:], o, P[f'{p}/layer_norm/layer_norm_scale'], P[f'{p}/layer_norm/layer_norm_bias'])
+            o, _ = self._cross_fwd(P, f'{p}/decoder_vanilla_attention', h, enc, cfg.dec_heads, ops.MASK_KEYPAD, len_enc, 0.0, 0)
+            h, _ = ops.residual_fwd(h, o, P[f'{p}/layer_norm_1/layer_norm_scale'], P[f'{p}/layer_norm_1/layer_norm_bias'])
+            h, _ = self._ffn_fwd(P, p, 2, h, 0.0, 0)
+            x = np.concatenate([cache[:, :, bi, :], h], 1)
+            new_cache.append(x[:, :, None, :])
+        cache = np.concatenate(new_cache, 2)
+        return ops.tfdense_fwd(x[:, -1, :], P[f'{n}/decoder/decoder_fc/kernel']), cache
+
+    def infer_beam(self, P, features, len_feas, beam_size, length_penalty_weight=0.0):
+        """build_infer_graph with beam_size > 1 (TransformerTPE.py:314-319): best-beam ids [B, steps] (not masked past
+        <eos>, as the reference returns them), CTC greedy preds, and the full beam_decode_rerank result."""
+        assert not self.is_train
+        st = self.forward(P, {'feature': features, 'len_fea': len_feas})
+        res = beam_decode_rerank(self, P, st['enc_out'], st['len_enc'], beam_size, length_penalty_weight)
+        return res[2], st['preds_am'], res
+
     def infer(self, P, features, len_feas):
         assert not self.is_train
         cfg = self.cfg
@@ -477,24 +510,7 @@ class OracleTPE:
         i = 0
         max_steps = min(T + 50, cfg.max_len)
         while (not finished.all()) and i < max_steps:
-            emb = P[f'{n}/embedding'][preds]
-            x = emb + (emb + ops.timing_signal(preds.shape[1], emb.shape[-1], emb.dtype))
-            new_cache = []
-            for bi in range(nb):
-                p = f'{n}/decoder/block_{bi}'
-                pa = f'{p}/decoder_self_attention'
-                qkv = ops.dense_fwd(x, P[f'{pa}/qkv_transform/kernel'], P[f'{pa}/qkv_transform/bias'])
-                q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-                a, _ = ops.mha_core_fwd(q[:, -1:], k, v, cfg.dec_heads, ops.MASK_NONE)
-                o = ops.dense_fwd(a, P[f'{pa}/output_transform/kernel'], P[f'{pa}/output_transform/bias'])
-                h, _ = ops.residual_fwd(x[:, -1:], o, P[f'{p}/layer_norm/layer_norm_scale'], P[f'{p}/layer_norm/layer_norm_bias'])
-                o, _ = self._cross_fwd(P, f'{p}/decoder_vanilla_attention', h, enc, cfg.dec_heads, ops.MASK_KEYPAD, len_enc, 0.0, 0)
-                h, _ = ops.residual_fwd(h, o, P[f'{p}/layer_norm_1/layer_norm_scale'], P[f'{p}/layer_norm_1/layer_norm_bias'])
-                h, _ = self._ffn_fwd(P, p, 2, h, 0.0, 0)
-                x = np.concatenate([cache[:, :, bi, :], h], 1)
-                new_cache.append(x[:, :, None, :])
-            cache = np.concatenate(new_cache, 2)
-            cur_logit = ops.tfdense_fwd(x[:, -1, :], P[f'{n}/decoder/decoder_fc/kernel'])
+            cur_logit, cache = self._cached_step(P, preds, cache, enc, len_enc)
             cur_ids = cur_logit.argmax(-1).astype(np.int32)
             preds = np.concatenate([preds, cur_ids[:, None]], 1)
             finished = finished | (cur_ids == cfg.eos)
@@ -504,6 +520,71 @@ class OracleTPE:
         preds = preds[:, 1:]
         not_padding = (np.arange(preds.shape[1])[None, :] < len_decoded[:, None]).astype(np.int32)
         return preds * not_padding, st['preds_am'], len_decoded
+
+
+def _log_softmax(x):
+    m = x.max(-1, keepdims=True)
+    return x - (m + np.log(np.exp(x - m).sum(-1, keepdims=True)))
+
+
+def _top_k(x, k):
+    """tf.nn.top_k(sorted=True): descending, equal values by lower index."""
+    idx = np.argsort(-x, axis=-1, kind='stable')[..., :k]
+    return np.take_along_axis(x, idx, -1), idx.astype(np.int32)
+
+
+REF_INF = 1e10     # `inf = 1e10`, st/models/decoders/transformer_decoder.py:14
+
+
+def beam_decode_rerank(model: 'OracleTPE', P, enc, len_enc, beam_size, length_penalty_weight):
+    """Transformer_Decoder.beam_decode_rerank (st/models/decoders/transformer_decoder.py:248-431) with lambda_lm = 0 (z_lm
+    is zeros there, :309).  Returns (preds_sorted [B, beam, steps], scores_sorted [B, beam], best preds [B, steps],
+    len_decoded [B * beam] in the UNSORTED beam order the reference returns, :431)."""
+    cfg = model.cfg
+    n = cfg.name
+    B, T, _ = enc.shape
+    K = beam_size
+    f32 = np.float32
+    enc = np.repeat(enc, K, axis=0)                                   # tile + reshape: rows b * K + j  (:258-262)
+    len_enc = np.repeat(len_enc, K)
+    R = B * K
+    preds = np.full((R, 1), cfg.sos, np.int32)                         # token_init (:265)
+    len_decoded = np.ones(R, np.int32)
+    scores = np.tile(np.array([0.0] + [-REF_INF] * (K - 1), f32), B)   # (:269-270)
+    finished = np.zeros(R, bool)
+    nb, d = cfg.dec_blocks, cfg.dec_units
+    cache = np.zeros((R, 0, nb, d), enc.dtype)
+    base = np.repeat(np.arange(B), K)
+    max_steps = min(T + 50, cfg.max_len)
+    i = 0
+    while (not finished.all()) and i < max_steps:                      # not_finished (:375-383)
+        cur_logit, cache = model._cached_step(P, preds, cache, enc, len_enc)
+        z = _log_softmax(cur_logit.astype(f32))
+        next_scores, next_preds = _top_k(z, K)                         # (:341)
+        fin = finished.astype(f32)[:, None]
+        next_preds = next_preds * (1 - finished.astype(np.int32)[:, None]) + finished.astype(np.int32)[:, None] * cfg.eos   # get_bias_preds
+        b = np.tile(np.array([0.0] + [-REF_INF] * (K - 1), f32)[None, :], (R, 1))
+        next_scores = (next_scores * (1 - fin) + b * fin).astype(f32)  # get_bias_scores
+        sc = (scores[:, None] + next_scores).astype(f32).reshape(B, K * K)
+        ln = (len_decoded[:, None] + (next_preds != cfg.eos).astype(np.int32)).reshape(B, K * K)
+        lp = np.power((5 + ln) / (5 + 1), length_penalty_weight)       # float64, as int / int in TF (:353)
+        sc = (sc / lp.astype(f32)).astype(f32)
+        _, k_idx = _top_k(sc, K)                                       # (:357)
+        k_idx = base * K * K + k_idx.reshape(-1)
+        len_decoded = ln.reshape(-1)[k_idx]
+        scores = sc.reshape(-1)[k_idx]
+        nxt = next_preds.reshape(-1)[k_idx]
+        parent = k_idx // K
+        preds = np.concatenate([preds[parent], nxt[:, None]], 1)
+        cache = cache[parent]
+        finished = finished | (nxt == cfg.eos)                         # (:368-369) sic: the old flags are NOT re-ordered by parent
+        i += 1
+    len_decoded = len_decoded - (1 - finished.astype(np.int32))
+    preds = preds[:, 1:]
+    s_sorted, order = _top_k(scores.reshape(B, K), K)
+    order = base * K + order.reshape(-1)
+    preds_sorted = preds[order].reshape(B, K, -1)
+    return preds_sorted, s_sorted, preds_sorted[:, 0, :], len_decoded
 
 
 def train_step(model: OracleTPE, P, M, V, batch, global_step, warmup_steps, peak, decay_steps, specaug_params=None):

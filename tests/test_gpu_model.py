@@ -161,6 +161,45 @@ def test_fp32_greedy_ids_bit_exact_and_ctc_preds():
     assert np.array_equal(model.last['len_decoded'], rlen)
 
 
+@pytest.mark.parametrize('case,beam,lpw,max_len,seed,boost', [
+    ('lut', 4, 0.0, 12, 4, 0.2), ('lut', 4, 0.2, 12, 5, 0.2), ('costt', 3, 0.2, 30, 6, 0.2), ('lut', 2, 0.6, 9, 7, 0.2), ('lut', 8, 0.0, 16, 8, 0.2),
+    ('lut', 4, 0.2, 30, 9, 0.16), ('costt', 4, 0.0, 30, 10, 0.17), ('lut', 3, 1.0, 30, 11, 0.15), ('lut', 4, 0.2, 30, 12, 0.0)])
+def test_fp32_beam_search_ids_bit_exact(case, beam, lpw, max_len, seed, boost):
+    """beam_decode_rerank (transformer_decoder.py:248-431) through TransformerTPE.infer with beam_size > 1: sorted
+    hypotheses, best ids and lengths equal the oracle's bit for bit in fp32 mode; scores to 1e-5.  max_len 9 / 16 stop
+    on and off the host's 8-step check; 30 lets every hypothesis reach <eos> when it can."""
+    args = ge.tiny_args(compute_dtype='fp32', **CASES[case])
+    args.beam_size, args.length_penalty_weight, args.max_len = beam, lpw, max_len
+    model = make_model(args, is_train=False)
+    P = perturb(model, seed=seed)
+    rng = np.random.default_rng(seed)
+    # decoder_fc has no bias: a common offset on the decoder's LayerNorm biases times a constant added to the <eos> column
+    # raises the <eos> logit by about 0.5 * 16 * boost, enough for hypotheses to finish at different steps
+    fc = [k for k in P if k.endswith('decoder_fc/kernel')][0]
+    for k in P:
+        if '/decoder/block_' in k and k.endswith('layer_norm_bias'):
+            P[k] = (P[k] + 0.5).astype(np.float32)
+    P[fc] = (P[fc] + 0.3 * rng.standard_normal(P[fc].shape)).astype(np.float32)
+    P[fc][:, args.eos_idx] += boost
+    model.store.load_params(P)
+    batch = make_batch(B=3, Traw=30, V=11, L=5, U=3, dim_raw=4, ragged=True, seed=seed)
+    preds, preds_am = model.infer(batch['feature'], batch['len_fea'])
+    cfg = ge.oracle_cfg_from_args(args).zero_dropout()
+    ob = oracle_batch(batch)
+    rp, rpam, (r_sorted, r_scores, _, r_len) = OracleTPE(cfg, is_train=False).infer_beam(
+        {k: v.astype(np.float64) for k, v in P.items()}, ob['feature'], ob['len_fea'], beam, lpw)
+    (p_sorted, scores, _), = [model.last['beams']]
+    assert preds.shape == rp.shape, (preds.shape, rp.shape)
+    assert np.array_equal(p_sorted, r_sorted), (p_sorted, r_sorted)
+    assert np.array_equal(preds, rp)
+    assert np.array_equal(preds_am, rpam)
+    assert np.array_equal(model.last['len_decoded'], r_len)
+    live = r_scores > -1e9
+    assert np.array_equal(scores > -1e9, live)
+    assert np.abs(scores - r_scores)[live].max() < 1e-5 * max(np.abs(r_scores[live]).max(), 1.0)
+    print('beam case', case, beam, lpw, 'steps', rp.shape[1], 'of', max_len, 'len_decoded', r_len.tolist(), 'best', rp.tolist())
+
+
 @pytest.mark.parametrize('bucket_mb,overlap', [(None, '1'), (0.004, '1'), (0.004, '0')])
 def test_train_steps_follow_oracle_adam_and_lr(bucket_mb, overlap, monkeypatch):
     """bucket_mb 0.004: ~40 gradient buckets of 1024 elements, each updated by its own Adam launch on the side stream

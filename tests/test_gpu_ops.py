@@ -468,3 +468,71 @@ def test_adam_matches_tf_formula():
         p, m, v = O.adam_step(p, 0.5 * g, m, v, lr, t)
     assert relerr(host(pd)[:n], p) < 1e-6 and relerr(host(vd)[:n], v) < 1e-6
     assert relerr(host(sh)[:n], p) < 1e-2
+
+
+def _np_topk(x, k):
+    idx = np.argsort(-x, axis=-1, kind='stable')[..., :k]
+    return np.take_along_axis(x, idx, -1), idx.astype(np.int32)
+
+
+@pytest.mark.parametrize('R,V,k', [(1, 5, 5), (12, 11, 4), (128, 10000, 4), (7, 300, 16)])
+def test_beam_topk_matches_numpy(R, V, k):
+    rng = np.random.default_rng(R + V)
+    x = rng.standard_normal((R, V)).astype(np.float32)
+    x[:, V // 2] = x[:, 0]                           # ties: the lower index wins
+    if R > 1:
+        x[1, :] = 0.25                               # a constant row: ids 0..k-1
+    sc, ids = ops.beam_topk(torch.from_numpy(x).to(DEV), k)
+    m = x.max(-1, keepdims=True)
+    z = x - (m + np.log(np.exp((x - m).astype(np.float64)).sum(-1, keepdims=True))).astype(np.float32)
+    rs, ri = _np_topk(z, k)
+    assert np.array_equal(ids.cpu().numpy(), ri)
+    assert np.abs(sc.cpu().numpy() - rs).max() < 1e-5
+
+
+@pytest.mark.parametrize('B,beam,lpw', [(1, 1, 0.0), (5, 4, 0.0), (33, 4, 0.2), (3, 8, 0.6), (4, 3, 1.0)])
+def test_beam_prune_matches_numpy(B, beam, lpw):
+    """the candidate table of transformer_decoder.py:316-373 restated in numpy on random beam states"""
+    rng = np.random.default_rng(B * 10 + beam)
+    R, eos, INF = B * beam, 3, np.float32(1e10)
+    ns = np.sort(-np.abs(rng.standard_normal((R, beam))).astype(np.float32), axis=1)[:, ::-1].copy()
+    ni = rng.integers(0, 9, size=(R, beam)).astype(np.int32)
+    scores = (-np.abs(rng.standard_normal(R)) * 3).astype(np.float32)
+    scores[rng.random(R) < 0.15] = -INF               # beams that were never alive
+    ln = rng.integers(1, 9, size=R).astype(np.int32)
+    fin = (rng.random(R) < 0.3).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    o_sc, o_ln, o_fin, o_tok, o_par = ops.beam_prune(t(ns), t(ni), t(scores), t(ln), t(fin), cnt, beam, eos, lpw)
+    f = fin[:, None]
+    nxt = ni * (1 - f) + f * eos
+    bias = np.tile(np.array([0.0] + [-INF] * (beam - 1), np.float32)[None], (R, 1))
+    nsb = (ns * (1 - f).astype(np.float32) + bias * f.astype(np.float32)).astype(np.float32)
+    cand = (scores[:, None] + nsb).astype(np.float32).reshape(B, beam * beam)
+    cl = (ln[:, None] + (nxt != eos)).reshape(B, beam * beam)
+    cand = (cand / np.power((5 + cl) / 6, lpw).astype(np.float32)).astype(np.float32)
+    _, kidx = _np_topk(cand, beam)
+    flat = (np.arange(B)[:, None] * beam * beam + kidx).reshape(-1)
+    r_tok = nxt.reshape(-1)[flat]
+    r_fin = fin | (r_tok == eos)
+    assert np.array_equal(o_par.cpu().numpy(), flat // beam)
+    assert np.array_equal(o_tok.cpu().numpy(), r_tok)
+    assert np.array_equal(o_ln.cpu().numpy(), cl.reshape(-1)[flat])
+    assert np.array_equal(o_fin.cpu().numpy(), r_fin)
+    assert np.array_equal(o_sc.cpu().numpy(), cand.reshape(-1)[flat])       # same fp32 operations in the same order
+    assert int(cnt.item()) == int((1 - r_fin).sum())
+    # a step enqueued after the loop has ended copies the state through
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cnt2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    p_sc, p_ln, p_fin, p_tok, p_par = ops.beam_prune(t(ns), t(ni), t(scores), t(ln), t(fin), cnt2, beam, eos, lpw, prev_unfinished=zero)
+    assert np.array_equal(p_sc.cpu().numpy(), scores) and np.array_equal(p_ln.cpu().numpy(), ln) and np.array_equal(p_fin.cpu().numpy(), fin)
+    assert np.array_equal(p_par.cpu().numpy(), np.arange(R)) and (p_tok.cpu().numpy() == eos).all() and int(cnt2.item()) == 0
+
+
+@pytest.mark.parametrize('shape,dtype', [((12, 7, 32), torch.bfloat16), ((5, 3), torch.int32), ((128, 250, 1536), torch.bfloat16)])
+def test_gather_rows(shape, dtype):
+    rng = np.random.default_rng(shape[0])
+    src = torch.from_numpy(rng.integers(-100, 100, size=shape).astype(np.float32)).to(DEV).to(dtype)
+    idx = torch.from_numpy(rng.integers(0, shape[0], size=shape[0]).astype(np.int32)).to(DEV)
+    out = ops.gather_rows(src, idx)
+    assert torch.equal(out, src[idx.long()])
