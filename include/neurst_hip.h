@@ -277,6 +277,22 @@ int neurst_beam_prune(const float* next_scores, const int32_t* next_ids, const f
 int neurst_gather_rows(const void* src, void* dst, const int32_t* idx, int64_t rows, int64_t row_bytes, int64_t src_stride,
                        int64_t dst_stride, void* stream);
 
+/* Input pipeline, host side (pure host code, callable without a GPU).  Replaces what the reference
+ * gets from TensorFlow's tf.TFRecordReader / tf.parse_single_example / tf.python_io.TFRecordWriter
+ * (st/tools/tftools/tfRecord.py:107-150 writer, :460-824 readers; `*.recode` files, :848-855).
+ * neurst_crc32c: CRC-32C (Castagnoli) of a byte range, unmasked; the container stores rotr(crc, 15) + 0xa282ead8.
+ * neurst_tfrecord_scan: walks a whole file image (e.g. a read-only mapping): record r has its payload at
+ *   buf + offsets[r], lengths[r] bytes.  Returns the number of records in the file (only the first max_records are
+ *   written; call with max_records = 0 to count), or NEURST_E_INVALID for a truncated file or - with verify_crc - a
+ *   length or payload whose checksum does not match (the message names the record and byte position).
+ * neurst_example_bytes_feature: in a serialized tf.train.Example, the first value of the bytes-list feature `key`
+ *   (what FixedLenFeature([], tf.string) + tf.decode_raw read, :639-672): *offset / *size relative to `record`.
+ *   NEURST_E_INVALID when the key is absent or the message malformed, NEURST_E_UNSUPPORTED when it is not a bytes list. */
+uint32_t neurst_crc32c(const void* data, int64_t nbytes);
+int64_t neurst_tfrecord_scan(const void* buf, int64_t nbytes, int64_t* offsets, int64_t* lengths, int64_t max_records,
+                             int verify_crc);
+int neurst_example_bytes_feature(const void* record, int64_t nbytes, const char* key, int64_t* offset, int64_t* size);
+
 /* kernel self-test: one 16x16xK MFMA tile product through the same fragment loaders the
  * GEMM / attention kernels use (A [16,K], B^T [16,K] -> C [16,16] fp32). */
 int neurst_selftest_mma(const void* A, const void* Bt, float* C, int64_t K, int dtype, void* stream);
