@@ -293,6 +293,12 @@ int64_t neurst_tfrecord_scan(const void* buf, int64_t nbytes, int64_t* offsets, 
                              int verify_crc);
 int neurst_example_bytes_feature(const void* record, int64_t nbytes, const char* key, int64_t* offset, int64_t* size);
 
+/* Dev-loop metric (host code): Levenshtein distance between two id sequences - what
+ * `editdistance.eval` gives batch_cer / batch_wer (st/tools/textTools.py:34-70).  sid (may be NULL) receives the
+ * substitutions / insertions / deletions of the alignment that st/tools/wer.py:124-151 picks (smallest total per cell,
+ * ties in the order substitution, insertion, deletion).  Returns the distance, or NEURST_E_INVALID. */
+int64_t neurst_edit_distance(const int32_t* ref, int64_t nref, const int32_t* hyp, int64_t nhyp, int64_t* sid);
+
 /* kernel self-test: one 16x16xK MFMA tile product through the same fragment loaders the
  * GEMM / attention kernels use (A [16,K], B^T [16,K] -> C [16,16] fp32). */
 int neurst_selftest_mma(const void* A, const void* Bt, float* C, int64_t K, int dtype, void* stream);

@@ -162,3 +162,38 @@ malformed:
   neurst_set_error("example_bytes_feature: malformed Example message");
   return NEURST_E_INVALID;
 }
+
+// ------------------------------------------------------------------------------------------------ dev-loop metrics
+// Edit distance between two id sequences.  Replaces `editdistance.eval` in batch_cer / batch_wer
+// (st/tools/textTools.py:34-70: plain Levenshtein distance) and, when `sid` is given, also returns the alignment counts
+// of st/tools/wer.py:124-151: each cell takes the candidate with the smallest substitutions + insertions + deletions,
+// ties in the order substitution/match, insertion, deletion (Python's min() keeps the first of equal candidates).
+#include <vector>
+
+extern "C" int64_t neurst_edit_distance(const int32_t* ref, int64_t nref, const int32_t* hyp, int64_t nhyp, int64_t* sid) {
+  if (nref < 0 || nhyp < 0 || (nref > 0 && !ref) || (nhyp > 0 && !hyp)) {
+    neurst_set_error("edit_distance: bad args");
+    return NEURST_E_INVALID;
+  }
+  struct Cell { int64_t s, i, d; int64_t sum() const { return s + i + d; } };
+  std::vector<Cell> prev(nhyp + 1), cur(nhyp + 1);
+  for (int64_t d = 0; d <= nhyp; ++d) prev[d] = Cell{0, d, 0};          // errors[0, :, 1] = arange
+  for (int64_t r = 0; r < nref; ++r) {
+    cur[0] = Cell{0, 0, r + 1};                                          // errors[:, 0, 2] = arange
+    for (int64_t d = 0; d < nhyp; ++d) {
+      Cell best = prev[d];
+      best.s += ref[r] != hyp[d];
+      Cell ins = cur[d];
+      ins.i += 1;
+      if (ins.sum() < best.sum()) best = ins;
+      Cell del = prev[d + 1];
+      del.d += 1;
+      if (del.sum() < best.sum()) best = del;
+      cur[d + 1] = best;
+    }
+    prev.swap(cur);
+  }
+  const Cell& e = prev[nhyp];
+  if (sid) { sid[0] = e.s; sid[1] = e.i; sid[2] = e.d; }
+  return e.sum();
+}
