@@ -181,7 +181,7 @@ def save2tfrecord_ctcbert(dataset, dir_save, size_file=5000000):
 
 
 # ------------------------------------------------------------------------------------------------ readers (:474-672)
-def _examples(dir_data, args, _shuffle, fields, epoch_seed=None, verify_crc=True):
+def _examples(dir_data, args, _shuffle, fields, epoch_seed=None, verify_crc=True, mode=None):
     """One pass over the files: tuples (id, feature, *fields).  Train mode cuts the raw frames to data.max_train_len
     (:656-657).  The file order is shuffled when `_shuffle` (random.shuffle, :624-625) and sorted otherwise; the
     reference additionally passes `shuffle=shuffle` - the imported FUNCTION, always true - to string_input_producer, so
@@ -191,7 +191,7 @@ def _examples(dir_data, args, _shuffle, fields, epoch_seed=None, verify_crc=True
     if _shuffle:
         random.Random(epoch_seed).shuffle(files)
     d = args.data
-    cut = d.max_train_len if args.mode == 'train' and d.max_train_len else None
+    cut = d.max_train_len if (mode or args.mode) == 'train' and d.max_train_len else None
     for path in files:
         rf = RecordFile(path, verify_crc=verify_crc)
         for i in range(len(rf)):
@@ -259,8 +259,9 @@ class TFReader:
     the device on the padded batch; bucketing uses the length AFTER it, as the reference does).  Train mode repeats the
     data for ever with a new file order per epoch (num_epochs=None, :629); any other mode makes one pass."""
 
-    def __init__(self, dir_tfdata, args, is_train=True, seed=0, pin_memory=False, verify_crc=True):
+    def __init__(self, dir_tfdata, args, is_train=True, seed=0, pin_memory=False, verify_crc=True, mode=None):
         self.dir_tfdata, self.args, self.is_train = dir_tfdata, args, is_train
+        self.mode = mode or args.mode          # `mode`: a dev reader inside a training run (args.mode stays 'train')
         self.seed, self.pin, self.verify_crc = seed, pin_memory, verify_crc
         if not args.list_bucket_boundaries:      # arguments.py:77-87
             if args.bucket_boundaries:
@@ -282,9 +283,9 @@ class TFReader:
         epoch = 0
         while True:
             yield from self.read(self.dir_tfdata, self.args, _shuffle=self.is_train, transform=True,
-                                 epoch_seed=self.seed + epoch, verify_crc=self.verify_crc and epoch == 0)
+                                 epoch_seed=self.seed + epoch, verify_crc=self.verify_crc and epoch == 0, mode=self.mode)
             epoch += 1
-            if self.args.mode != 'train':
+            if self.mode != 'train':
                 return
 
     def transformed_len(self, example):
