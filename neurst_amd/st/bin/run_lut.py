@@ -75,8 +75,9 @@ def train(args, max_steps=None):
         return dev_cer, dev_wer, dev_bleu
 
     def save(global_step):
-        path = '{}/model-{}.npz'.format(args.dir_checkpoint, global_step)
-        checkpointTools.save_checkpoint(path, model.store, global_step)
+        # checkpoint_format: 'npz' (default) or 'tf' = TensorBundle files a TensorFlow reader opens (build-side YAML key)
+        path = checkpointTools.save_checkpoint('{}/model-{}'.format(args.dir_checkpoint, global_step), model.store, global_step,
+                                               fmt=args.checkpoint_format)
         logging.info('Save model in %s.' % path)
 
     def check_save(dev_bleu, dev_wer, global_step):

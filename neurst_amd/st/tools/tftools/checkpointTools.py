@@ -1,16 +1,19 @@
-"""Checkpoints of the variable store under the reference's TF variable names and layouts - SURVEY 8(f) rank 1, partial.
+"""Checkpoints of the variable store under the reference's TF variable names and layouts - SURVEY 8(f) rank 1.
 
 Mirrors the reading interface of st/tools/tftools/checkpointTools.py:44-97 (`load_checkpoint(...).get_tensor`,
 `load_variable`, `list_variables`), what `tf.train.Saver` keeps for this model (`st/bin/run_lut.py:140-276`: variables,
 Adam slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power`, `global_step`) and st/tools/avg_checkpoints.py:46-117.
 
-Container: ONE numpy `.npz` (plain arrays, read with allow_pickle=False) - NOT TensorFlow's TensorBundle
-(`.index` / `.data-*`): no reference checkpoint exists in the repository to pin a bundle parser against, so that
-importer is left for a later round.  Variable names and array layouts are the TF ones (`[out, in]` for `dense`,
-`[in, out]` for `tf.layers.dense` kernels), so a bundle importer only has to produce this dict."""
+Two containers, told apart by the files present: TensorFlow's own TensorBundle (`<prefix>.index` + `<prefix>.data-*`,
+tensorBundle.py - what a reference-trained model is saved as) and ONE numpy `.npz` (plain arrays, read with
+allow_pickle=False; the default for writing).  Variable names and array layouts are the TF ones in both (`[out, in]` for
+`dense`, `[in, out]` for `tf.layers.dense` kernels).  A directory stands for its newest checkpoint as named by its
+`checkpoint` file - TF's text format (`model_checkpoint_path: "model-1000"`) or one file name per line."""
 import os
 
 import numpy as np
+
+from .tensorBundle import BundleReader, write_bundle
 
 ADAM_M, ADAM_V = '/Adam', '/Adam_1'
 
@@ -20,28 +23,66 @@ class CheckpointReader:
 
     def __init__(self, path):
         self.path = resolve(path)
-        self._z = np.load(self.path, allow_pickle=False)
+        if self.path.endswith('.npz'):
+            self._z, self._b = np.load(self.path, allow_pickle=False), None
+        else:
+            self._z, self._b = None, BundleReader(self.path)
 
     def get_tensor(self, name):
         name = name[:-2] if name.endswith(':0') else name
-        return np.array(self._z[name])
+        return np.array(self._z[name]) if self._b is None else self._b.get_tensor(name)
 
     def has_tensor(self, name):
-        return name in self._z.files
+        return name in self._z.files if self._b is None else self._b.has_tensor(name)
 
     def get_variable_to_shape_map(self):
-        return {k: list(self._z[k].shape) for k in self._z.files}
+        return {k: list(self._z[k].shape) for k in self._z.files} if self._b is None else self._b.get_variable_to_shape_map()
 
 
 def resolve(ckpt_dir_or_file):
-    """A directory means its newest checkpoint (tf.train.latest_checkpoint): the last line of `<dir>/checkpoint`."""
-    if os.path.isdir(ckpt_dir_or_file):
-        index = os.path.join(ckpt_dir_or_file, 'checkpoint')
+    """-> `<...>.npz`, or the prefix of a TensorBundle.  A directory means its newest checkpoint
+    (tf.train.latest_checkpoint)."""
+    p = ckpt_dir_or_file
+    if os.path.isdir(p):
+        index = os.path.join(p, 'checkpoint')
         if not os.path.exists(index):
-            raise ValueError("Couldn't find 'checkpoint' file or checkpoints in given directory %s" % ckpt_dir_or_file)
-        names = [l.strip() for l in open(index) if l.strip()]
-        return os.path.join(ckpt_dir_or_file, names[-1])
-    return ckpt_dir_or_file if ckpt_dir_or_file.endswith('.npz') else ckpt_dir_or_file + '.npz'
+            raise ValueError("Couldn't find 'checkpoint' file or checkpoints in given directory %s" % p)
+        lines = [l.strip() for l in open(index) if l.strip()]
+        newest = [l.split(':', 1)[1].strip().strip('"') for l in lines if l.startswith('model_checkpoint_path:')]
+        p = os.path.join(p, newest[-1] if newest else lines[-1])
+    if p.endswith('.npz') or os.path.exists(p + '.index'):
+        return p
+    return p + '.npz'
+
+
+def _note_in_state_file(full):
+    """appends the new checkpoint to `<dir>/checkpoint` in the format that file already has (TF's for bundles)"""
+    d, name = os.path.dirname(os.path.abspath(full)), os.path.basename(full)
+    state = os.path.join(d, 'checkpoint')
+    if full.endswith('.npz'):
+        with open(state, 'a') as f:
+            f.write(name + '\n')
+        return
+    older = []
+    if os.path.exists(state):
+        older = [l.split(':', 1)[1].strip().strip('"') for l in open(state) if l.startswith('all_model_checkpoint_paths:')]
+    with open(state, 'w') as f:
+        f.write('model_checkpoint_path: "%s"\n' % name)
+        for n in [o for o in older if o != name] + [name]:
+            f.write('all_model_checkpoint_paths: "%s"\n' % n)
+
+
+def _write(path, tensors, fmt):
+    if fmt not in (None, 'npz', 'tf'):
+        raise ValueError("checkpoint format must be 'npz' or 'tf'")
+    if fmt == 'tf' or (fmt is None and not path.endswith('.npz') and os.path.exists(path + '.index')):
+        full = path[:-4] if path.endswith('.npz') else path
+        write_bundle(full, tensors)
+    else:
+        full = path if path.endswith('.npz') else path + '.npz'
+        os.makedirs(os.path.dirname(os.path.abspath(full)), exist_ok=True)
+        np.savez(full, **tensors)
+    return full
 
 
 def load_checkpoint(ckpt_dir_or_file):
@@ -57,8 +98,9 @@ def list_variables(ckpt_dir_or_file):
     return [(k, m[k]) for k in sorted(m)]
 
 
-def save_checkpoint(path, store, global_step, beta1=0.9, beta2=0.98, slots=True):
-    """Writes `<path>.npz` (variables, Adam slots, beta powers, global_step) and appends it to `<dir>/checkpoint`."""
+def save_checkpoint(path, store, global_step, beta1=0.9, beta2=0.98, slots=True, fmt=None):
+    """Writes variables, Adam slots, beta powers and global_step as `<path>.npz` (default) or, with fmt='tf', as the
+    TensorBundle `<path>.index` / `<path>.data-00000-of-00001`, and notes it in `<dir>/checkpoint`."""
     out = store.export()
     if slots:
         for k, v in store.export(store.m).items():
@@ -69,11 +111,8 @@ def save_checkpoint(path, store, global_step, beta1=0.9, beta2=0.98, slots=True)
         out['beta2_power'] = np.float32(beta2 ** max(store.adam_t, 0) * beta2)
         out['adam_t'] = np.int64(store.adam_t)
     out['global_step'] = np.int64(int(global_step))
-    full = resolve(path)
-    os.makedirs(os.path.dirname(os.path.abspath(full)), exist_ok=True)
-    np.savez(full, **out)
-    with open(os.path.join(os.path.dirname(os.path.abspath(full)), 'checkpoint'), 'a') as f:
-        f.write(os.path.basename(full) + '\n')
+    full = _write(path, out, fmt)
+    _note_in_state_file(full)
     return full
 
 
@@ -109,13 +148,15 @@ def restore(ckpt_dir_or_file, store, assignment_map=None, slots=True, strict=Tru
         store.load_slots(m, v)
         if r.has_tensor('adam_t'):
             store.adam_t = int(r.get_tensor('adam_t'))
+        elif r.has_tensor('beta1_power'):      # a TensorFlow-written checkpoint: beta1_power = beta1^(t+1) (lstmModel.py:526-530, beta1 = 0.9)
+            store.adam_t = max(int(round(np.log(float(r.get_tensor('beta1_power'))) / np.log(0.9))) - 1, 0)
     return int(r.get_tensor('global_step')) if r.has_tensor('global_step') else 0
 
 
-def average_checkpoints(checkpoints, output_path):
+def average_checkpoints(checkpoints, output_path, fmt=None):
     """st/tools/avg_checkpoints.py:75-117: element-wise mean of every variable except global_step (Adam slots included,
     as the reference's list_variables loop does); the result carries global_step 0."""
-    checkpoints = [c for c in checkpoints if os.path.exists(resolve(c))]
+    checkpoints = [c for c in checkpoints if os.path.exists(resolve(c)) or os.path.exists(resolve(c) + '.index')]
     if not checkpoints:
         raise ValueError('None of the provided checkpoints exist.')
     names = [n for n, _ in list_variables(checkpoints[0]) if not n.startswith('global_step') and n != 'adam_t']
@@ -127,6 +168,4 @@ def average_checkpoints(checkpoints, output_path):
             acc[n] = t if n not in acc else acc[n] + t
     out = {n: (a / len(checkpoints)).astype(np.float32) for n, a in acc.items()}
     out['global_step'] = np.int64(0)
-    full = resolve(output_path)
-    np.savez(full, **out)
-    return full
+    return _write(output_path, out, fmt)

@@ -179,8 +179,9 @@ def test_grad_bucketer_two_rank_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
 
 
-def test_checkpoint_roundtrip_rename_and_average(tmp_path):
-    """.npz checkpoints under the TF variable names - save / list / load_variable / restore with a
+@pytest.mark.parametrize('fmt', [None, 'tf'])
+def test_checkpoint_roundtrip_rename_and_average(tmp_path, fmt):
+    """checkpoints (.npz, or fmt='tf': TensorBundle .index/.data) under the TF variable names - save / list / load_variable / restore with a
     scope rename / average (st/tools/tftools/checkpointTools.py:44-97, st/tools/avg_checkpoints.py:75-117)."""
     import torch
     from neurst_amd import ops
@@ -192,7 +193,8 @@ def test_checkpoint_roundtrip_rename_and_average(tmp_path):
     a.m += 0.25
     a.v += 0.5
     a.adam_t = 7
-    p1 = ck.save_checkpoint(str(tmp_path / 'model-100'), a, 100)
+    p1 = ck.save_checkpoint(str(tmp_path / 'model-100'), a, 100, fmt=fmt)
+    assert os.path.exists(p1 + '.index') == (fmt == 'tf')
     assert [n for n, _ in ck.list_variables(p1) if n.endswith('kernel')] == ['transformer/decoder/decoder_fc/kernel', 'transformer/encoder/encoder_fc/kernel']
     assert ck.load_variable(p1, 'transformer/encoder/encoder_fc/kernel:0').shape == (6, 4)
     assert ck.resolve(str(tmp_path)) == p1                     # directory -> newest checkpoint
@@ -208,8 +210,81 @@ def test_checkpoint_roundtrip_rename_and_average(tmp_path):
     with pytest.raises(ValueError):
         ck.restore(p1, c)                                      # without the map the names do not match
     a.params *= 3.0
-    p2 = ck.save_checkpoint(str(tmp_path / 'model-200'), a, 200)
-    avg = ck.average_checkpoints([p1, p2, str(tmp_path / 'missing')], str(tmp_path / 'averaged'))
+    p2 = ck.save_checkpoint(str(tmp_path / 'model-200'), a, 200, fmt=fmt)
+    assert ck.resolve(str(tmp_path)) == p2
+    if fmt == 'tf':
+        assert open(tmp_path / 'checkpoint').read().split('\n')[0] == 'model_checkpoint_path: "model-200"'
+    avg = ck.average_checkpoints([p1, p2, str(tmp_path / 'missing')], str(tmp_path / 'averaged'), fmt=fmt)
     d = VariableStore(specs, torch.device('cpu'), ops.F32, seed=5)
     assert ck.restore(avg, d) == 0
     assert all(np.allclose(v, 2.0 * b.export()[k]) for k, v in d.export().items())
+
+
+def test_tensor_bundle_container(tmp_path):
+    """tensorBundle.py: the LevelDB-format index (prefix-compressed keys, several blocks, footer magic), block and
+    tensor checksums, a snappy-compressed block, dtype / shape coverage and a TensorFlow-written state file."""
+    import struct
+    from neurst_amd.st.tools.tftools import checkpointTools as ck
+    from neurst_amd.st.tools.tftools import tensorBundle as TB
+    rng = np.random.default_rng(0)
+    t = {'transformer/encoder/block_%d/ff_hidden/dense/kernel' % i: rng.standard_normal((7, 5)).astype(np.float32) for i in range(300)}
+    t.update({'global_step': np.int64(1234), 'beta1_power': np.float32(0.9 ** 8), 'x/empty': np.zeros((0, 3), np.float32),
+              'x/i32': np.arange(6, dtype=np.int32).reshape(2, 3), 'x/f64': rng.standard_normal(3), 'x/bool': np.array([True, False])})
+    prefix = str(tmp_path / 'model-5')
+    TB.write_bundle(prefix, t)
+    index = open(prefix + '.index', 'rb').read()
+    assert struct.unpack('<Q', index[-8:])[0] == 0xdb4775248b80fb57 and len(index) > 3 * 4096      # several data blocks
+    assert len(index) < sum(len(k) + 30 for k in t)                                                # keys are prefix-compressed
+    r = TB.BundleReader(prefix)
+    assert sorted(r.entries) == sorted(t)
+    for k, v in t.items():
+        g = r.get_tensor(k)
+        assert g.dtype == np.asarray(v).dtype and g.shape == np.asarray(v).shape and np.array_equal(g, v), k
+    assert [k for k, _ in TB.read_table(prefix + '.index')] == sorted([b''] + [k.encode() for k in t])
+    # through the checkpoint interface, with a TF-style state file naming it
+    (tmp_path / 'checkpoint').write_text('model_checkpoint_path: "model-5"\nall_model_checkpoint_paths: "model-4"\nall_model_checkpoint_paths: "model-5"\n')
+    assert ck.resolve(str(tmp_path)) == prefix
+    assert int(ck.load_variable(str(tmp_path), 'global_step')) == 1234
+    assert dict(ck.list_variables(prefix))['x/i32'] == [2, 3]
+    # corruption is reported: a flipped bit in the data file (tensor crc), in the index (block crc), a bad magic number
+    data = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    data[10] ^= 1
+    open(str(tmp_path / 'bad.data-00000-of-00001'), 'wb').write(bytes(data))
+    open(str(tmp_path / 'bad.index'), 'wb').write(index)
+    bad = TB.BundleReader(str(tmp_path / 'bad'))
+    first = [k for k, e in bad.entries.items() if e['offset'] <= 10 < e['offset'] + e['size']][0]
+    with pytest.raises(ValueError, match='checksum'):
+        bad.get_tensor(first)
+    flipped = bytearray(index)
+    flipped[100] ^= 1
+    open(str(tmp_path / 'bad2.index'), 'wb').write(bytes(flipped))
+    with pytest.raises(ValueError, match='checksum'):
+        TB.read_table(str(tmp_path / 'bad2.index'))
+    open(str(tmp_path / 'bad3.index'), 'wb').write(index[:-1] + b'\x00')
+    with pytest.raises(ValueError, match='magic'):
+        TB.read_table(str(tmp_path / 'bad3.index'))
+    # snappy: literal 'abcd' + copy(offset 4, length 7); a literal longer than 60 bytes; an overlapping copy of one byte
+    assert TB._snappy_decompress(bytes([11, 0x0c]) + b'abcd' + bytes([((7 - 4) << 2) | 1, 4])) == b'abcdabcdabc'
+    long = bytes(range(70))
+    assert TB._snappy_decompress(bytes([70, 60 << 2, 69]) + long) == long
+    assert TB._snappy_decompress(bytes([9, 0x00]) + b'z' + bytes([((8 - 1) << 2) | 2, 1, 0])) == b'z' * 9
+    with pytest.raises(ValueError):
+        TB._snappy_decompress(bytes([5, 0x00]) + b'z')
+    # a hand-built table whose only data block is snappy-compressed (type byte 1) reads like the plain one
+    blk = TB._BlockBuilder()
+    blk.add(b'', b'\x08\x01')
+    blk.add(b'aa', b'v1')
+    blk.add(b'ab', b'v2')
+    raw = blk.finish()
+    comp = bytes([len(raw), (len(raw) - 1) << 2]) + raw        # one literal element
+    body = comp + b'\x01' + struct.pack('<I', TB._crc(comp + b'\x01'))
+    idx = TB._BlockBuilder(1)
+    idx.add(b'ab', TB._put_varint(0) + TB._put_varint(len(comp)))
+    metab, idxb = TB._BlockBuilder().finish(), idx.finish()
+    off_meta = len(body)
+    body += metab + b'\x00' + struct.pack('<I', TB._crc(metab + b'\x00'))
+    off_idx = len(body)
+    body += idxb + b'\x00' + struct.pack('<I', TB._crc(idxb + b'\x00'))
+    footer = TB._put_varint(off_meta) + TB._put_varint(len(metab)) + TB._put_varint(off_idx) + TB._put_varint(len(idxb))
+    open(str(tmp_path / 'snappy.index'), 'wb').write(body + footer + bytes(40 - len(footer)) + struct.pack('<Q', TB.MAGIC))
+    assert TB.read_table(str(tmp_path / 'snappy.index')) == [(b'', b'\x08\x01'), (b'aa', b'v1'), (b'ab', b'v2')]

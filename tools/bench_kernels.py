@@ -65,6 +65,22 @@ def bench_gemm():
         print(line)
 
 
+def bench_wgrad():
+    """weight-gradient shapes: plain TN split-K against the same launch with the fused bias gradient, per split"""
+    rnd = lambda *s: (torch.rand(*s, device=DEV) * 2 - 1).to(torch.bfloat16)
+    for name, M, N, K, which in [('ffn1', 3072, 768, 16000, 1), ('ffn2', 768, 3072, 16000, 1), ('qkv', 2304, 768, 16000, 1), ('out', 768, 768, 16000, 1)]:
+        A, B = rnd(K, M), rnd(K, N)          # A = dY [rows, out], B = x [rows, in]
+        C = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+        bsum = torch.zeros(M, device=DEV, dtype=torch.float32)
+        fl = 2.0 * M * N * K
+        cs, _ = timeit(lambda: ops.colsum(A, bsum))
+        for sk in (1, 2, 3, 4, 5, 6, 8):
+            plain, _ = timeit(lambda: ops.gemm(A, B, C, M, N, K, M, N, N, 1, 0, accumulate=True, split_k=sk))
+            fused, _ = timeit(lambda: ops.gemm_wgrad_bias(A, B, C, bsum, which, M, N, K, M, N, N, split_k=sk))
+            print('wgrad %-5s M=%5d N=%5d K=%5d split=%d%s  plain %7.1f us %6.1f TF/s | +bias-grad %7.1f us %6.1f TF/s | colsum alone %5.1f us' % (
+                name, M, N, K, sk, '*' if sk == ops.pick_split_k(M, N, K) else ' ', plain, fl / plain / 1e6, fused, fl / fused / 1e6, cs), flush=True)
+
+
 def bench_attn():
     B, H, T, dh = 32, 8, 500, 96
     d = H * dh
@@ -105,6 +121,8 @@ def bench_ln():
 
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if what == 'wgrad':
+        bench_wgrad()
     if what in ('gemm', 'all'):
         bench_gemm()
     if what in ('attn', 'all'):
