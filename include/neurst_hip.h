@@ -130,11 +130,12 @@ int neurst_dropout_add_layernorm_fwd(const void* x, void* y_inout_z, const float
 /* dz (gradient wrt x, and wrt y when rate==0) and dy = dz*mask*scale (dy may be NULL or == dz
  * when rate == 0); dgamma/dbeta accumulate (+=) in fp32; partial: NULL = workgroups add their column partials to dgamma/dbeta with fp32 atomics (fast, summation order
  * varies); or a [2*nblk*C] fp32 workspace = deterministic two-pass reduction
- * where nblk = neurst_layernorm_bwd_blocks(rows). */
+ * where nblk = neurst_layernorm_bwd_blocks(rows).  dbias (may be NULL): += column sums of dy (fp32) - the gradient of the
+ * bias of the dense layer that produced y, so that layer's weight-gradient GEMM can skip its operand sum. */
 int64_t neurst_layernorm_bwd_blocks(int64_t rows);
 int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z, const float* gamma,
                                      const float* mean, const float* rstd, void* dz, void* dy,
-                                     float* dgamma, float* dbeta, float* partial,
+                                     float* dgamma, float* dbeta, float* partial, float* dbias,
                                      int64_t rows, int64_t C, float rate, uint32_t key,
                                      const int32_t* lens, int64_t T, int dtype, void* stream);
 

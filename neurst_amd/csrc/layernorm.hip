@@ -180,26 +180,28 @@ __global__ void ln_fwd_generic(const T* __restrict__ x, T* __restrict__ yz, cons
 }
 
 // ------------------------------------------------------------------ backward (vector path)
-template <typename T, int VEC, int NCH>
+// DB: also dbias[col] += sum over rows of dy (the gradient of the bias of the dense layer that produced y: the weight-
+// gradient GEMM of that layer then needs no operand sum)
+template <typename T, int VEC, int NCH, bool DB>
 __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ gamma,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dz,
                                                    T* __restrict__ dy, float* __restrict__ partial, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int64_t rows, int C, uint32_t thr,
+                                                   float* __restrict__ dbeta, float* __restrict__ dbias, int64_t rows, int C, uint32_t thr,
                                                    float scale, uint32_t key, uint32_t inner0, int idx32,
                                                    const int32_t* __restrict__ lens, int64_t Tn) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sm = reinterpret_cast<float*>(smem_raw);  // [2][nw][C]
+  float* sm = reinterpret_cast<float*>(smem_raw);  // [2 or 3][nw][C]
   const int nw = blockDim.x >> 6;           // 4 or 8 waves: one row per wave in flight, so more waves = more rows in flight
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunks = C / VEC;
   const float invC = 1.f / (float)C;
-  float dgam[NCH][VEC], dbet[NCH][VEC], gv[NCH][VEC];
+  float dgam[NCH][VEC], dbet[NCH][VEC], gv[NCH][VEC], dbia[DB ? NCH : 1][VEC];
   const bool pvec = (((uintptr_t)gamma) & 15) == 0;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     int ch = lane + 64 * c;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { dgam[c][j] = 0.f; dbet[c][j] = 0.f; }
+    for (int j = 0; j < VEC; ++j) { dgam[c][j] = 0.f; dbet[c][j] = 0.f; if constexpr (DB) dbia[c][j] = 0.f; }
     load_param<VEC>(gamma, ch, ch < nchunks, pvec, gv[c]);
   }
   for (int64_t row = (int64_t)blockIdx.x * nw + w; row < rows; row += (int64_t)gridDim.x * nw) {
@@ -246,6 +248,10 @@ __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, c
           for (int j = 0; j < VEC; ++j) o[j] = ln_keep(key, inner0, idx32, off + j, thr) ? o[j] * scale : 0.f;
           VecIO<T, VEC>::store(dy + off, o);
         }
+        if constexpr (DB) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dbia[c][j] += o[j];
+        }
       }
     }
   }
@@ -258,15 +264,17 @@ __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, c
       for (int j = 0; j < VEC; ++j) {
         sm[(0 * nw + w) * C + ch * VEC + j] = dgam[c][j];
         sm[(1 * nw + w) * C + ch * VEC + j] = dbet[c][j];
+        if constexpr (DB) sm[(2 * nw + w) * C + ch * VEC + j] = dbia[c][j];
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+  for (int i = threadIdx.x; i < (DB ? 3 : 2) * C; i += blockDim.x) {
     int which = i / C, col = i % C;
     float s = 0.f;
     for (int ww = 0; ww < nw; ++ww) s += sm[(which * nw + ww) * C + col];
-    if (partial) partial[((int64_t)blockIdx.x * 2 + which) * C + col] = s;
+    if (which == 2) atomicAdd(dbias + col, s);
+    else if (partial) partial[((int64_t)blockIdx.x * 2 + which) * C + col] = s;
     else atomicAdd((which ? dbeta : dgamma) + col, s);   // a few hundred adds per address: cheaper than a second launch
   }
 }
@@ -379,8 +387,8 @@ extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const f
 
 extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z, const float* gamma, const float* mean,
                                                 const float* rstd, void* dz, void* dy, float* dgamma, float* dbeta, float* partial,
-                                                int64_t rows, int64_t C, float rate, uint32_t key, const int32_t* lens, int64_t T,
-                                                int dtype, void* stream) {
+                                                float* dbias, int64_t rows, int64_t C, float rate, uint32_t key, const int32_t* lens,
+                                                int64_t T, int dtype, void* stream) {
   NEURST_CHECK_ARG(rows > 0 && C > 0 && rate >= 0.f && rate < 1.f, "layernorm_bwd: bad args");
   NEURST_CHECK_ARG(rate == 0.f || (dy && dy != dz), "layernorm_bwd: dropout needs a separate dy buffer");
   NEURST_CHECK_ARG(!lens || T > 0, "layernorm_bwd: lens given without T");
@@ -389,7 +397,9 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   int grid = (int)neurst_layernorm_bwd_blocks(rows);
   hipStream_t s = as_stream(stream);
   const int nthr = ln_bwd_threads(rows);
-  size_t shmem = (size_t)2 * (nthr / 64) * C * sizeof(float);
+  // dbias rides in the same kernel when its third [waves][C] LDS array still fits; otherwise a column sum of dy follows
+  const bool fuse_db = dbias && (size_t)3 * (nthr / 64) * C * sizeof(float) <= 150 * 1024;
+  size_t shmem = (size_t)(fuse_db ? 3 : 2) * (nthr / 64) * C * sizeof(float);
   bool vec = false;
   // column sums: workgroups add their LDS-reduced partials straight into dgamma / dbeta (measured 45 us against
   // 38 + 12 us for partial buffers plus a second reduction launch); `partial` is kept in the ABI and, when given,
@@ -397,10 +407,12 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   const bool use_partial = partial != nullptr;
   const uint32_t inner0 = fmix32(key);
   const int idx32 = (double)rows * (double)C < 4294967296.0;
-#define BWD_VEC(TT, VEC, NCH)                                                                                                \
-  if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec<TT, VEC, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-  ln_bwd_vec<TT, VEC, NCH><<<grid, nthr, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, use_partial ? partial : nullptr, \
-                                                    dgamma, dbeta, rows, (int)C, thr, sc, key, inner0, idx32, lens, T)
+#define BWD_VEC_DB(TT, VEC, NCH, DB)                                                                                         \
+  if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec<TT, VEC, NCH, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+  ln_bwd_vec<TT, VEC, NCH, DB><<<grid, nthr, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, use_partial ? partial : nullptr, \
+                                                        dgamma, dbeta, dbias, rows, (int)C, thr, sc, key, inner0, idx32, lens, T)
+#define BWD_VEC(TT, VEC, NCH) \
+  if (fuse_db) { BWD_VEC_DB(TT, VEC, NCH, true); } else { BWD_VEC_DB(TT, VEC, NCH, false); }
 #define BWD_DISPATCH(TT, VEC)                                         \
   switch (ln_nch(C, VEC)) {                                           \
     case 1: BWD_VEC(TT, VEC, 1); break;                               \
@@ -418,7 +430,12 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   }
 #undef BWD_DISPATCH
 #undef BWD_VEC
+#undef BWD_VEC_DB
   NEURST_CHECK_LAUNCH("dropout_add_layernorm_bwd");
+  if (dbias && !(vec && fuse_db)) {   // generic path, or a row too wide for the third LDS array
+    const int rc = neurst_colsum(thr ? dy : dz, dbias, rows, C, C, dtype, 1, stream);
+    if (rc != NEURST_OK) return rc;
+  }
   if (vec && use_partial) {
     ln_bwd_reduce<<<(int)cdiv64(2 * C, 64), 1024, 0, s>>>(partial, dgamma, dbeta, grid, (int)C);
     NEURST_CHECK_LAUNCH("layernorm_bwd_reduce");

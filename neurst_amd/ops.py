@@ -254,9 +254,9 @@ def dropout_add_layernorm_fwd(x, y_inout, gamma, beta, rate, key, lens=None, T=0
     return out, mean, rstd
 
 
-def dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dgamma, dbeta, rate, key, lens=None, T=0, deterministic=False):
+def dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dgamma, dbeta, rate, key, lens=None, T=0, deterministic=False, dbias=None):
     """deterministic=True: column sums through per-workgroup partial buffers and a second reduction launch instead of
-    fp32 atomics straight into dgamma / dbeta."""
+    fp32 atomics straight into dgamma / dbeta.  dbias (fp32 [C]): += column sums of dy."""
     C = z.shape[-1]
     rows = z.numel() // C
     dz = torch.empty_like(z)
@@ -266,7 +266,7 @@ def dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dgamma, dbeta, rate, k
         nblk = _C.neurst_layernorm_bwd_blocks(rows)
         partial = torch.empty(2 * nblk * C, dtype=torch.float32, device=z.device)
     _chk(_C.neurst_dropout_add_layernorm_bwd(_p(_c(dout)), _p(z), _p(gamma), _p(mean), _p(rstd), _p(dz), _p(dy), _p(dgamma), _p(dbeta),
-                                              _p(partial), rows, C, rate, key, _p(lens), T, dt_of(z), _s()), 'dropout_add_layernorm_bwd')
+                                              _p(partial), _p(dbias), rows, C, rate, key, _p(lens), T, dt_of(z), _s()), 'dropout_add_layernorm_bwd')
     return dz, dy
 
 

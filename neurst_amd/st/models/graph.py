@@ -137,6 +137,7 @@ class Tape:
         self.grads = {}
         self.keep = {}
         self.relu_outputs = set()   # ids of tensors produced by a fused ReLU: their gradient is gated where it is produced
+        self.bias_hooks = {}        # id(dense output) -> BiasGradHook (tools/utils.py): who accumulates that layer's bias gradient
 
     def push(self, fn, early=False):
         """early=True: the node's output gradient is set by the loss itself (the CTC head), so backward may run it first,

@@ -2,6 +2,8 @@
 (st/models/tools/utils.py: dense :367-398, ff_hidden :401-410, residual :324-337,
 multihead_attention :479-554).  Each call launches the forward HIP kernel(s) and, when a
 Tape is active, registers the matching backward launches."""
+import os
+
 import torch
 
 from .. import graph as G
@@ -32,6 +34,19 @@ def _wgrad(dy2, x2, param, layout, bias=None):
             ops.gemm(x2, dy2, param.grad, n_in, n_out, M, n_in, n_out, n_out, True, False, accumulate=True, split_k=sk)
 
 
+# off by default: measured on LUT config 2 the third column sum makes ln_bwd (main stream) slower by more than the operand
+# sum costs the weight-gradient GEMMs (second stream): 16.49 ms per step with it, 16.32 without
+_FUSE_BIAS_GRAD = os.environ.get('NEURST_FUSE_BIAS_GRAD', '0') != '0'
+
+
+class BiasGradHook:
+    """Set by a dense layer on its output; `residual` marks it taken when it accumulates the bias gradient itself."""
+    __slots__ = ('bias', 'taken')
+
+    def __init__(self, bias):
+        self.bias, self.taken = bias, False
+
+
 def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient, early_backward=False):
     g = G.current()
     n_in = inputs.shape[-1]
@@ -47,6 +62,11 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient, early_b
     if tape is not None:
         if relu:
             tape.relu_outputs.add(id(out))
+        # a `residual` that consumes `out` directly sums dy over the rows anyway (LayerNorm's dgamma / dbeta pass): it
+        # takes the bias gradient along (fused_bias_grad) and the weight-gradient GEMM below runs without its operand sum
+        hook = None
+        if b is not None and not relu and _FUSE_BIAS_GRAD:
+            hook = tape.bias_hooks[id(out)] = BiasGradHook(b)
 
         def bwd():
             dy = tape.pop(out)
@@ -55,11 +75,12 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient, early_b
             dy2 = _flat2d(dy)
             if dy2.dtype != x2.dtype:
                 raise TypeError('gradient dtype {} does not match operand dtype {}'.format(dy2.dtype, x2.dtype))
+            bw = None if (hook is not None and hook.taken) else b
             side = g.side_stream_for(M, dy2.device)
             if side is not None:     # small layer: weight (and bias) gradient beside the data-gradient chain
-                g.run_on_side(side, lambda: _wgrad(dy2, x2, w, layout, b), dy2, x2)
+                g.run_on_side(side, lambda: _wgrad(dy2, x2, w, layout, bw), dy2, x2)
             else:
-                _wgrad(dy2, x2, w, layout, b)
+                _wgrad(dy2, x2, w, layout, bw)
             g.param_grad_done(w)
             if b is not None:
                 g.param_grad_done(b)
@@ -120,11 +141,16 @@ def residual(inputs, outputs, dropout_rate, site=None, mask_lens=None):
     out, mean, rstd = ops.dropout_add_layernorm_fwd(inputs, outputs, scale.master, bias.master, rate, key, mask_lens, T)
     tape = g.tape
     if tape is not None:
+        hook = tape.bias_hooks.get(id(outputs))
+        if hook is not None:
+            hook.taken = True
+
         def bwd():
             dout = tape.pop(out)
             if dout is None:
                 return
-            dz, dy = ops.dropout_add_layernorm_bwd(dout, outputs, scale.master, mean, rstd, scale.grad, bias.grad, rate, key, mask_lens, T)
+            dz, dy = ops.dropout_add_layernorm_bwd(dout, outputs, scale.master, mean, rstd, scale.grad, bias.grad, rate, key, mask_lens, T,
+                                                   dbias=hook.bias.grad if hook is not None else None)
             g.param_grad_done(scale)
             g.param_grad_done(bias)
             # With rate == 0 dy IS dz (one buffer): the producer of `outputs` reads it in the very next

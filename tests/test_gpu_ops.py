@@ -536,3 +536,25 @@ def test_gather_rows(shape, dtype):
     idx = torch.from_numpy(rng.integers(0, shape[0], size=shape[0]).astype(np.int32)).to(DEV)
     out = ops.gather_rows(src, idx)
     assert torch.equal(out, src[idx.long()])
+
+
+@pytest.mark.parametrize('rows,C,rate,dtype', [(37, 16, 0.0, torch.float32), (300, 768, 0.1, torch.float32), (5000, 768, 0.1, torch.bfloat16),
+                                               (64, 4096, 0.1, torch.bfloat16), (33, 20, 0.2, torch.float32)])
+def test_layernorm_bwd_bias_gradient_output(rows, C, rate, dtype):
+    """dbias += column sums of dy: the same numbers a column sum of the returned dy gives (fused in the kernel for rows
+    that fit its LDS arrays, a colsum launch for C = 4096 and for the generic path at C = 20)"""
+    g = torch.Generator(device='cpu').manual_seed(rows)
+    z = torch.randn(rows, C, generator=g).to(DEV).to(dtype)
+    dout = torch.randn(rows, C, generator=g).to(DEV).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    mean, rstd = z.float().mean(-1), (z.float().var(-1, unbiased=False) + 1e-6).rsqrt()
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dbias = torch.full((C,), 0.5, device=DEV)
+    dz, dy = ops.dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dg, db, rate, 77, dbias=dbias)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz2, dy2 = ops.dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dg2, db2, rate, 77)
+    assert torch.equal(dz, dz2) and torch.equal(dy, dy2)
+    assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
+    want = 0.5 + dy.double().sum(0)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2 * max(1.0, float(rows) ** 0.5 / 8)      # bf16: dy is rounded after the fp32 sum was taken
+    assert (dbias.double() - want).abs().max().item() < tol * max(1.0, want.abs().max().item()), (dbias.double() - want).abs().max().item()
