@@ -156,3 +156,34 @@ def test_mean_of_tower_gradients_equals_full_batch_gradient():
     rel = (acc - full).norm().item() / full.norm().item()
     cos = torch.dot(acc, full).item() / (acc.norm().item() * full.norm().item())
     assert rel < 2e-2 and cos > 0.9995, (rel, cos)
+
+
+def test_beam_kernels_at_full_vocabulary_and_batch():
+    """beam search bookkeeping at LUT scale (32 utterances x 4 hypotheses, V = 10000): top-k agrees with torch.topk of
+    the log-softmax, a pruning step keeps the best candidates in order, and parents / gathers stay inside the utterance"""
+    beam, R = 4, B * 4
+    g = torch.Generator(device='cpu').manual_seed(5)
+    logits = (torch.randn(R, V, generator=g) * 3).to(DEV)
+    sc, ids = ops.beam_topk(logits, beam)
+    ref = torch.log_softmax(logits.double(), -1)
+    rs, ri = ref.topk(beam, dim=-1)
+    assert torch.equal(ids.long(), ri)                        # random fp32 logits: no ties
+    assert (sc.double() - rs).abs().max().item() < 1e-5
+    scores = torch.tensor(([0.0] + [-1e10] * (beam - 1)) * B, device=DEV)
+    len_dec = torch.ones(R, dtype=torch.int32, device=DEV)
+    fin = torch.zeros(R, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(3, dtype=torch.int32, device=DEV)
+    for step in range(3):                                     # three steps: from one live hypothesis to a full beam
+        n_sc, n_len, n_fin, tok, par = ops.beam_prune(sc, ids, scores, len_dec, fin, cnt[step:step + 1], beam, 3, 0.2,
+                                                      prev_unfinished=cnt[step - 1:step] if step else None)
+        s2 = n_sc.view(B, beam)
+        assert (s2[:, :-1] >= s2[:, 1:]).all()                # survivors come out best first
+        assert torch.equal(par // beam, torch.arange(R, device=DEV, dtype=torch.int32) // beam)      # parents stay in their utterance
+        cand = ((scores[:, None] + sc) / (((5.0 + (len_dec[:, None] + 1).double()) / 6.0) ** 0.2).float()).view(B, beam * beam)
+        assert torch.allclose(s2[:, 0], cand.max(-1).values, rtol=1e-6)
+        if step == 0:
+            assert (par % beam == 0).all()                    # only hypothesis 0 was alive
+        scores, len_dec, fin = n_sc, n_len, n_fin
+        logits = ops.gather_rows(logits, par) + 0.1 * step    # as the caches are re-ordered in the real loop
+        sc, ids = ops.beam_topk(logits, beam)
+    assert int(cnt[2].item()) == int((fin == 0).sum().item()) and (len_dec >= 1).all() and (len_dec <= 4).all()
