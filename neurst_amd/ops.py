@@ -243,12 +243,16 @@ def mha_bwd(q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B
 
 
 # ---- layer norm ------------------------------------------------------------------------
-def dropout_add_layernorm_fwd(x, y_inout, gamma, beta, rate, key, lens=None, T=0):
+def dropout_add_layernorm_fwd(x, y_inout, gamma, beta, rate, key, lens=None, T=0, bufs=None):
+    """bufs = (out, mean, rstd) to write into buffers of the caller (decoding loops) instead of new ones."""
     C = x.shape[-1]
     rows = x.numel() // C
-    out = torch.empty_like(x)
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if bufs is not None:
+        out, mean, rstd = bufs
+    else:
+        out = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     _chk(_C.neurst_dropout_add_layernorm_fwd(_p(_c(x)), _p(_c(y_inout)), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, C, rate, key,
                                               _p(lens), T, dt_of(x), _s()), 'dropout_add_layernorm_fwd')
     return out, mean, rstd
@@ -284,11 +288,12 @@ def build_decoder_input(labels, len_labels, sos):
     return inp
 
 
-def embedding_fwd(ids, table, out_dtype, rate, key, pos0=0, signal_len=None):
+def embedding_fwd(ids, table, out_dtype, rate, key, pos0=0, signal_len=None, out=None):
     B, Ln = ids.shape
     V, D = table.shape
     sig = timing_signal_table(signal_len or (pos0 + Ln), D, ids.device)
-    out = torch.empty((B, Ln, D), dtype=torch_dtype(out_dtype), device=ids.device)
+    if out is None:
+        out = torch.empty((B, Ln, D), dtype=torch_dtype(out_dtype), device=ids.device)
     sig_ptr = sig.data_ptr() + pos0 * D * 4
     _chk(_C.neurst_embedding_fwd(_p(_c(ids)), _p(table), sig_ptr, _p(out), B, Ln, D, V, rate, key, out_dtype, _s()), 'embedding_fwd')
     return out

@@ -37,13 +37,13 @@ class Decoder(object):
             decoder_input.len_labels = None
         return decoder_input
 
-    def embedding(self, ids, dropout_rate=0.0, site=None, pos0=0, signal_len=None):
+    def embedding(self, ids, dropout_rate=0.0, site=None, pos0=0, signal_len=None, out=None):
         """decoder.py:198-204 lookup fused with `x += x + timing` and the dropout that follow it in
         transformer_decoder.py:193-199."""
         g = G.current()
         table = self.embed_table
         rate, key = g.rate(dropout_rate), g.key(site)
-        out = ops.embedding_fwd(ids, table.master, g.dtype, rate, key, pos0=pos0, signal_len=signal_len)
+        out = ops.embedding_fwd(ids, table.master, g.dtype, rate, key, pos0=pos0, signal_len=signal_len, out=out)
         tape = g.tape
         if tape is not None:
             def bwd():

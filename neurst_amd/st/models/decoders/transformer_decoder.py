@@ -65,48 +65,18 @@ class Transformer_Decoder(Decoder):
         g = G.current()
         assert g.tape is None
         B, T = encoded.shape[0], encoded.shape[1]
-        d, H = self.num_cell_units, self.num_heads
-        dh = d // H
         dev = encoded.device
         max_steps = int(min(T + 50, self.args.max_len))
-        tdt = ops.torch_dtype(g.dtype)
         preds = torch.zeros((B, max_steps), dtype=torch.int32, device=dev)
         cur = torch.full((B, 1), int(self.start_token), dtype=torch.int32, device=dev)   # token fed at this step
         finished = torch.zeros(B, dtype=torch.int32, device=dev)
         len_decoded = torch.ones(B, dtype=torch.int32, device=dev)
         unfinished_hist = torch.zeros(max_steps, dtype=torch.int32, device=dev)   # rows still decoding after each step
         CHECK_EVERY = 8      # host looks at the stop condition every 8 steps (one read back), not every step
-        kv_cache = [torch.empty((B, max_steps, 2 * d), dtype=tdt, device=dev) for _ in range(self.num_blocks)]
-        mem_kv = []
-        for i in range(self.num_blocks):   # encoder-side K/V of every block, once
-            with G.variable_scope('block_{}'.format(i)), G.variable_scope('decoder_vanilla_attention'):
-                mem_kv.append(dense(encoded, 2 * d, name='kv_transform'))
-        lse_self = torch.empty((B, H, 1), dtype=torch.float32, device=dev)
+        run = _CachedDecoderStep(self, encoded, len_encoded, beam=1, max_steps=max_steps)
         step = 0
         while step < max_steps:
-            x = self.embedding(cur, dropout_rate=0.0, pos0=step, signal_len=max_steps)     # [B,1,d]
-            for i in range(self.num_blocks):
-                with G.variable_scope('block_{}'.format(i)):
-                    with G.variable_scope('decoder_self_attention'):
-                        qkv = dense(x, 3 * d, name='qkv_transform')                                # [B,1,3d]
-                        kv_cache[i][:, step, :].copy_(qkv[:, 0, d:])                                # buffer plumbing (strided D2D copy)
-                        a = torch.empty((B, 1, d), dtype=tdt, device=dev)
-                        kc = kv_cache[i].view(-1)
-                        ops.mha_fwd_strided(qkv.view(-1), kc, kc[d:], a, lse_self, 3 * d, 2 * d, 2 * d, d,
-                                            3 * d, max_steps * 2 * d, max_steps * 2 * d, d, B, H, 1, step + 1, dh, ops.MASK_NONE, None)
-                        o = dense(a, d, name='output_transform')
-                    x = residual(x, o, 0.0)
-                    with G.variable_scope('decoder_vanilla_attention'):
-                        q = dense(x, d, name='q_transform')
-                        a = torch.empty((B, 1, d), dtype=tdt, device=dev)
-                        mk = mem_kv[i].view(-1)
-                        ops.mha_fwd_strided(q.view(-1), mk, mk[d:], a, lse_self, d, 2 * d, 2 * d, d, d, T * 2 * d, T * 2 * d, d,
-                                            B, H, 1, T, dh, ops.MASK_KEYPAD, len_encoded)
-                        o = dense(a, d, name='output_transform')
-                    x = residual(x, o, 0.0)
-                    x = residual(x, ff_hidden(x, hidden_size=4 * d, output_size=d, activation='relu'), 0.0)
-                    g.name_counts = {}   # the same layer_norm / ff_hidden names are reused every step
-            cur_logit = tf_layers_dense(x.view(B, d), self.dim_output, use_bias=False, name='decoder_fc', out_dtype=ops.F32)
+            cur_logit = run.step(cur, step)
             ops.greedy_step(cur_logit, preds, finished, len_decoded, unfinished_hist[step:step + 1], step, self.end_token)
             cur.copy_(preds[:, step:step + 1])
             step += 1
@@ -138,11 +108,9 @@ class Transformer_Decoder(Decoder):
         lpw = float(self.args.length_penalty_weight or 0.0)
         B, T = encoded.shape[0], encoded.shape[1]
         R = B * K
-        d, H = self.num_cell_units, self.num_heads
-        dh = d // H
+        d = self.num_cell_units
         dev = encoded.device
         max_steps = int(min(T + 50, self.args.max_len))
-        tdt = ops.torch_dtype(g.dtype)
         INF = 1e10
         preds = torch.zeros((R, max_steps), dtype=torch.int32, device=dev)
         preds_next = torch.zeros_like(preds)
@@ -152,39 +120,11 @@ class Transformer_Decoder(Decoder):
         scores = torch.tensor(([0.0] + [-INF] * (K - 1)) * B, dtype=torch.float32, device=dev)
         unfinished_hist = torch.zeros(max_steps, dtype=torch.int32, device=dev)
         CHECK_EVERY = 8
-        kv_cache = [torch.empty((R, max_steps, 2 * d), dtype=tdt, device=dev) for _ in range(self.num_blocks)]
-        kv_next = [torch.empty_like(c) for c in kv_cache]
-        mem_kv = []
-        for i in range(self.num_blocks):   # encoder-side K/V of every block, once per utterance (shared by its hypotheses)
-            with G.variable_scope('block_{}'.format(i)), G.variable_scope('decoder_vanilla_attention'):
-                mem_kv.append(dense(encoded, 2 * d, name='kv_transform'))
-        lse = torch.empty((R, H, 1), dtype=torch.float32, device=dev)
+        run = _CachedDecoderStep(self, encoded, len_encoded, beam=K, max_steps=max_steps)
+        kv_next = [torch.empty_like(c) for c in run.kv_cache]
         step = 0
         while step < max_steps:
-            x = self.embedding(cur, dropout_rate=0.0, pos0=step, signal_len=max_steps)     # [R,1,d]
-            for i in range(self.num_blocks):
-                with G.variable_scope('block_{}'.format(i)):
-                    with G.variable_scope('decoder_self_attention'):
-                        qkv = dense(x, 3 * d, name='qkv_transform')
-                        kv_cache[i][:, step, :].copy_(qkv[:, 0, d:])
-                        a = torch.empty((R, 1, d), dtype=tdt, device=dev)
-                        kc = kv_cache[i].view(-1)
-                        ops.mha_fwd_strided(qkv.view(-1), kc, kc[d:], a, lse, 3 * d, 2 * d, 2 * d, d,
-                                            3 * d, max_steps * 2 * d, max_steps * 2 * d, d, R, H, 1, step + 1, dh, ops.MASK_NONE, None)
-                        o = dense(a, d, name='output_transform')
-                    x = residual(x, o, 0.0)
-                    with G.variable_scope('decoder_vanilla_attention'):
-                        q = dense(x, d, name='q_transform')
-                        a = torch.empty((R, 1, d), dtype=tdt, device=dev)
-                        mk = mem_kv[i].view(-1)
-                        # B "batches" of K queries each: the hypotheses of an utterance share its keys and values
-                        ops.mha_fwd_strided(q.view(-1), mk, mk[d:], a, lse, d, 2 * d, 2 * d, d, K * d, T * 2 * d, T * 2 * d, K * d,
-                                            B, H, K, T, dh, ops.MASK_KEYPAD, len_encoded)
-                        o = dense(a, d, name='output_transform')
-                    x = residual(x, o, 0.0)
-                    x = residual(x, ff_hidden(x, hidden_size=4 * d, output_size=d, activation='relu'), 0.0)
-                    g.name_counts = {}
-            cur_logit = tf_layers_dense(x.view(R, d), self.dim_output, use_bias=False, name='decoder_fc', out_dtype=ops.F32)
+            cur_logit = run.step(cur, step)
             next_scores, next_ids = ops.beam_topk(cur_logit, K)
             scores, len_decoded, finished, tokens, parents = ops.beam_prune(next_scores, next_ids, scores, len_decoded, finished,
                                                                             unfinished_hist[step:step + 1], K, int(self.end_token), lpw,
@@ -192,9 +132,10 @@ class Transformer_Decoder(Decoder):
             ops.gather_rows(preds, parents, out=preds_next)
             preds, preds_next = preds_next, preds
             preds[:, step].copy_(tokens)
-            for i in range(self.num_blocks):      # only the step + 1 positions written so far
-                ops.gather_rows(kv_cache[i], parents, out=kv_next[i], row_bytes=(step + 1) * 2 * d * kv_cache[i].element_size())
-            kv_cache, kv_next = kv_next, kv_cache
+            row_bytes = (step + 1) * 2 * d * run.kv_cache[0].element_size()      # only the step + 1 positions written so far
+            for i in range(self.num_blocks):
+                ops.gather_rows(run.kv_cache[i], parents, out=kv_next[i], row_bytes=row_bytes)
+            kv_next = run.swap_caches(kv_next)
             cur.copy_(tokens.view(R, 1))
             step += 1
             if step % CHECK_EVERY == 0 or step == max_steps:
@@ -213,3 +154,95 @@ class Transformer_Decoder(Decoder):
         s_sorted = np.take_along_axis(sc, order, 1)
         ld = len_decoded.cpu().numpy() - (1 - finished.cpu().numpy())
         return [p, s_sorted, s_sorted], p[:, 0, :], ld
+
+
+class _CachedDecoderStep:
+    """decoder_with_caching_impl + decoder_fc on the last position (:123-182, :65-75) for R = B * beam rows, for the decoding
+    loops: the variables are looked up and every buffer is allocated ONCE, a step is ~55 launches through the C ABI with
+    no allocation and no scope bookkeeping (the layer functions of tools/utils.py cost ~2x the host time per launch,
+    and a decoding step is bound by exactly that).  Self-attention K/V projections go straight into the per-block cache
+    [R, max_steps, 2d] (row `step`); the encoder-side K/V of every block are projected once per utterance, and the `beam`
+    hypotheses of an utterance attend to them as `beam` queries of one batch entry."""
+
+    def __init__(self, dec, encoded, len_encoded, beam, max_steps):
+        g = G.current()
+        self.g, self.dec, self.beam, self.max_steps = g, dec, beam, max_steps
+        self.len_encoded = len_encoded
+        B, T = encoded.shape[0], encoded.shape[1]
+        d, H = dec.num_cell_units, dec.num_heads
+        self.B, self.T, self.d, self.H, self.dh = B, T, d, H, d // H
+        R = self.R = B * beam
+        dev, tdt = encoded.device, ops.torch_dtype(g.dtype)
+        V = self.V = dec.dim_output
+
+        def lin(name, n_out, n_in):
+            with G.variable_scope(name):
+                return g.get_variable('kernel', [n_out, n_in]), g.get_variable('bias', [n_out])
+
+        def ln(name):
+            with G.variable_scope(name):
+                return g.get_variable('layer_norm_scale', [d]).master, g.get_variable('layer_norm_bias', [d]).master
+        self.blocks, self.mem_kv = [], []
+        for i in range(dec.num_blocks):
+            with G.variable_scope('block_{}'.format(i)):
+                with G.variable_scope('decoder_self_attention'):
+                    qkv_w, qkv_b = lin('qkv_transform', 3 * d, d)
+                    so_w, so_b = lin('output_transform', d, d)
+                with G.variable_scope('decoder_vanilla_attention'):
+                    q_w, q_b = lin('q_transform', d, d)
+                    co_w, co_b = lin('output_transform', d, d)
+                    self.mem_kv.append(dense(encoded, 2 * d, name='kv_transform').view(-1))
+                with G.variable_scope('ff_hidden'):
+                    f1_w, f1_b = lin('dense', 4 * d, d)
+                    f2_w, f2_b = lin('dense_1', d, 4 * d)
+                blk = dict(q_w=qkv_w.w[:d], q_b=qkv_b.master[:d], kv_w=qkv_w.w[d:], kv_b=qkv_b.master[d:], so_w=so_w.w, so_b=so_b.master,
+                           cq_w=q_w.w, cq_b=q_b.master, co_w=co_w.w, co_b=co_b.master, f1_w=f1_w.w, f1_b=f1_b.master, f2_w=f2_w.w,
+                           f2_b=f2_b.master, ln=[ln('layer_norm'), ln('layer_norm_1'), ln('layer_norm_2')])
+                self.blocks.append(blk)
+            g.name_counts = {}
+        with G.variable_scope('decoder_fc'):
+            self.fc_w = g.get_variable('kernel', [d, V]).w
+        new = lambda *shape, dt=tdt: torch.empty(shape, dtype=dt, device=dev)
+        self.kv_cache = [new(R, max_steps, 2 * d) for _ in range(dec.num_blocks)]
+        self.x = [new(R, 1, d), new(R, 1, d)]
+        self.q, self.a, self.o, self.h = new(R, d), new(R, d), new(R, d), new(R, 4 * d)
+        self.mean, self.rstd = new(R, dt=torch.float32), new(R, dt=torch.float32)
+        self.lse = new(R * H, dt=torch.float32)
+        self.logits = new(R, V, dt=torch.float32)
+
+    def swap_caches(self, other):
+        """beam search re-orders the caches into `other`; returns the old buffers for the next re-ordering"""
+        old, self.kv_cache = self.kv_cache, other
+        return old
+
+    def step(self, cur, step):
+        """cur [R, 1] int32: the token fed at this step -> fp32 logits [R, V] (a buffer that the next step overwrites)"""
+        R, d, H, dh, T, K, ms = self.R, self.d, self.H, self.dh, self.T, self.beam, self.max_steps
+        gemm, lnf = ops.gemm, ops.dropout_add_layernorm_fwd
+        x, y = self.x
+        q, a, o, h = self.q, self.a, self.o, self.h
+        stats = (self.mean, self.rstd)
+        self.dec.embedding(cur, dropout_rate=0.0, pos0=step, signal_len=ms, out=x)
+        for blk, cache, mk in zip(self.blocks, self.kv_cache, self.mem_kv):
+            kc = cache.view(-1)
+            gemm(x, blk['q_w'], q, R, d, d, d, d, d, False, True, bias=blk['q_b'])
+            gemm(x, blk['kv_w'], kc[step * 2 * d:], R, 2 * d, d, d, d, ms * 2 * d, False, True, bias=blk['kv_b'])
+            ops.mha_fwd_strided(q, kc, kc[d:], a, self.lse, d, 2 * d, 2 * d, d, d, ms * 2 * d, ms * 2 * d, d, R, H, 1, step + 1, dh,
+                                ops.MASK_NONE, None)
+            gemm(a, blk['so_w'], o, R, d, d, d, d, d, False, True, bias=blk['so_b'])
+            lnf(x, o, blk['ln'][0][0], blk['ln'][0][1], 0.0, 0, None, 1, bufs=(y,) + stats)
+            x, y = y, x
+            gemm(x, blk['cq_w'], q, R, d, d, d, d, d, False, True, bias=blk['cq_b'])
+            # B "batches" of K queries each: the hypotheses of an utterance share its keys and values
+            ops.mha_fwd_strided(q, mk, mk[d:], a, self.lse, d, 2 * d, 2 * d, d, K * d, T * 2 * d, T * 2 * d, K * d, self.B, H, K, T, dh,
+                                ops.MASK_KEYPAD, self.len_encoded)
+            gemm(a, blk['co_w'], o, R, d, d, d, d, d, False, True, bias=blk['co_b'])
+            lnf(x, o, blk['ln'][1][0], blk['ln'][1][1], 0.0, 0, None, 1, bufs=(y,) + stats)
+            x, y = y, x
+            gemm(x, blk['f1_w'], h, R, 4 * d, d, d, d, 4 * d, False, True, bias=blk['f1_b'], relu=True)
+            gemm(h, blk['f2_w'], o, R, d, 4 * d, 4 * d, 4 * d, d, False, True, bias=blk['f2_b'])
+            lnf(x, o, blk['ln'][2][0], blk['ln'][2][1], 0.0, 0, None, 1, bufs=(y,) + stats)
+            x, y = y, x
+        self.x = [x, y]
+        gemm(x, self.fc_w, self.logits, R, self.V, d, d, self.V, self.V, False, False)
+        return self.logits
