@@ -116,6 +116,25 @@ def test_empty_truncated_and_corrupted_files_are_reported(tmp_path):
         R.RecordFile(str(tmp_path / 'huge.recode'))
 
 
+def test_native_parser_survives_mutated_files_under_sanitizers(tmp_path):
+    """tests/native/fuzz_records.cpp: csrc/records.cpp compiled for the host with AddressSanitizer + UBSan, fed bit-flipped,
+    truncated and random record files / Example payloads from exact-size heap buffers; every accepted view must lie
+    inside its record"""
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('no host compiler')
+    root = ge.ROOT
+    exe = str(tmp_path / 'fuzz_records')
+    subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-msse4.2', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
+                           '-I', os.path.join(root, 'include'), os.path.join(root, 'tests', 'native', 'fuzz_records.cpp'),
+                           os.path.join(root, 'neurst_amd', 'csrc', 'records.cpp'), '-o', exe])
+    out = subprocess.run([exe, '40000'], capture_output=True, text=True, timeout=300)
+    if out.returncode != 0 and 'ASan runtime does not come first' in out.stderr:
+        pytest.skip('the environment preloads a library ahead of the sanitizer runtime')
+    assert out.returncode == 0 and 'fuzz ok' in out.stdout, out.stdout[-500:] + out.stderr[-2000:]
+
+
 def _args(mode='train', **over):
     args = ge.tiny_args(compute_dtype='fp32', **over)
     args.mode = mode
