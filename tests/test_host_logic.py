@@ -288,3 +288,20 @@ def test_tensor_bundle_container(tmp_path):
     footer = TB._put_varint(off_meta) + TB._put_varint(len(metab)) + TB._put_varint(off_idx) + TB._put_varint(len(idxb))
     open(str(tmp_path / 'snappy.index'), 'wb').write(body + footer + bytes(40 - len(footer)) + struct.pack('<Q', TB.MAGIC))
     assert TB.read_table(str(tmp_path / 'snappy.index')) == [(b'', b'\x08\x01'), (b'aa', b'v1'), (b'ab', b'v2')]
+
+
+def test_avg_checkpoints_cli(tmp_path):
+    """st/tools/avg_checkpoints.py flags: --checkpoints / --prefix, and --num_last_checkpoints over the state file"""
+    from neurst_amd.st.tools import avg_checkpoints as avg
+    from neurst_amd.st.tools.tftools import checkpointTools as ck
+    from neurst_amd.st.tools.tftools import tensorBundle as TB
+    for step, scale in ((100, 1.0), (200, 3.0), (300, 5.0)):
+        TB.write_bundle(str(tmp_path / ('model-%d' % step)), {'w': np.full((2, 3), scale, np.float32), 'global_step': np.int64(step)})
+        ck._note_in_state_file(str(tmp_path / ('model-%d' % step)))
+    out = avg.main(['--checkpoints', 'model-100,model-200,model-999', '--prefix', str(tmp_path) + '/', '--output_path', str(tmp_path / 'avg_a')])
+    assert os.path.exists(out + '.index') and np.array_equal(ck.load_variable(out, 'w'), np.full((2, 3), 2.0, np.float32))
+    assert int(ck.load_variable(out, 'global_step')) == 0
+    out = avg.main(['--num_last_checkpoints', '2', '--prefix', str(tmp_path) + '/', '--output_path', str(tmp_path / 'avg_b'), '--format', 'npz'])
+    assert out.endswith('.npz') and np.array_equal(ck.load_variable(out, 'w'), np.full((2, 3), 4.0, np.float32))
+    with pytest.raises(ValueError):
+        avg.main(['--checkpoints', 'nope', '--prefix', str(tmp_path) + '/'])
