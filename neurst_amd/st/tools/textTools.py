@@ -33,40 +33,37 @@ def align_counts(reference, decoded):
 
 
 def unpadding(list_idx, eos_idx=None, min_idx=0, max_idx=None):
-    """:14-31 - cut at the first eos, then keep min_idx < id < max_idx"""
-    list_idx = np.asarray(list_idx)
+    """:14-31 - the ids before the first `eos_idx` that lie strictly between min_idx and max_idx (1-d array)"""
+    ids = np.asarray(list_idx)
     if eos_idx is not None:
-        end_idx = np.where(list_idx == eos_idx)[0]
-        end_idx = end_idx[0] if len(end_idx) > 0 else None
-        list_idx = list_idx[:end_idx]
-    list_idx = list_idx[np.where(list_idx > min_idx)]
+        hits = np.flatnonzero(ids == eos_idx)
+        if hits.size:
+            ids = ids[:hits[0]]
+    keep = ids > min_idx
     if max_idx is not None:
-        list_idx = list_idx[np.where(list_idx < max_idx)]
-    return list_idx
+        keep &= ids < max_idx
+    return ids[keep]
+
+
+def _error_counts(pairs):
+    """sum of edit distances and of reference lengths over (result, reference) sequence pairs"""
+    dist = length = 0
+    for res, ref in pairs:
+        dist += edit_distance(res, ref)
+        length += len(ref)
+    return dist, length
 
 
 def batch_cer(result, reference, eos_idx=None, min_idx=0, max_idx=None):
     """:34-47 -> (sum of edit distances over token ids, sum of reference lengths)"""
-    batch_dist = 0
-    batch_len = 0
-    for res, ref in zip(result, reference):
-        res = unpadding(res, eos_idx, min_idx, max_idx)
-        ref = unpadding(ref, eos_idx, min_idx, max_idx)
-        batch_dist += edit_distance(res, ref)
-        batch_len += len(ref)
-    return batch_dist, batch_len
+    clean = lambda row: unpadding(row, eos_idx, min_idx, max_idx)
+    return _error_counts((clean(res), clean(ref)) for res, ref in zip(result, reference))
 
 
 def batch_wer(result, reference, idx2token, unit, eos_idx=None, min_idx=0, max_idx=None, args=None):
-    """:50-70 -> the same over whitespace-separated words of the detokenised text"""
-    batch_dist = 0
-    batch_len = 0
-    for res, ref in zip(result, reference):
-        list_res_txt = array2text(res, unit, idx2token, eos_idx, min_idx, max_idx, args=args).split()
-        list_ref_txt = array2text(ref, unit, idx2token, eos_idx, min_idx, max_idx, args=args).split()
-        batch_dist += edit_distance(list_res_txt, list_ref_txt)
-        batch_len += len(list_ref_txt)
-    return batch_dist, batch_len
+    """:50-70 -> the same over the whitespace-separated words of the detokenised text"""
+    words = lambda row: array2text(row, unit, idx2token, eos_idx, min_idx, max_idx, args=args).split()
+    return _error_counts((words(res), words(ref)) for res, ref in zip(result, reference))
 
 
 def array2text(res, unit, idx2token, eos_idx=None, min_idx=0, max_idx=None, args=None, delimiter=None):
