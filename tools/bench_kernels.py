@@ -68,7 +68,10 @@ def bench_gemm():
 def bench_wgrad():
     """weight-gradient shapes: plain TN split-K against the same launch with the fused bias gradient, per split"""
     rnd = lambda *s: (torch.rand(*s, device=DEV) * 2 - 1).to(torch.bfloat16)
-    for name, M, N, K, which in [('ffn1', 3072, 768, 16000, 1), ('ffn2', 768, 3072, 16000, 1), ('qkv', 2304, 768, 16000, 1), ('out', 768, 768, 16000, 1)]:
+    shapes = [('ffn1', 3072, 768, 16000, 1), ('ffn2', 768, 3072, 16000, 1), ('qkv', 2304, 768, 16000, 1), ('out', 768, 768, 16000, 1)]
+    if os.environ.get('DECODER_SHAPES'):      # weight gradients of the decoder blocks: K = B * L = 1280 rows
+        shapes = [('dec out', 768, 768, 1280, 1), ('dec qkv', 2304, 768, 1280, 1), ('dec ffn1', 3072, 768, 1280, 1), ('dec ffn2', 768, 3072, 1280, 1)]
+    for name, M, N, K, which in shapes:
         A, B = rnd(K, M), rnd(K, N)          # A = dY [rows, out], B = x [rows, in]
         C = torch.zeros(M, N, device=DEV, dtype=torch.float32)
         bsum = torch.zeros(M, device=DEV, dtype=torch.float32)
