@@ -141,6 +141,11 @@ def main():
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='debug: every rank uses cuda:0 and the gloo backend (exercises the N>1 code path on a 1-GPU box; not a measurement)')
     a = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 on the way (RCCL
+    # prints a version banner there when its communicator comes up) is sent to stderr until the result is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get('NEURST_BENCH_WATCHDOG'):      # debug aid: dump every thread's stack if the run is still going after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['NEURST_BENCH_WATCHDOG']), exit=True)
@@ -257,7 +262,10 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             threads = min(os.cpu_count() or 1, 16)
             res['cpu_baseline'] = cpu_baseline(threads)
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(res), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
 
