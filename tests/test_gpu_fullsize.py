@@ -187,3 +187,23 @@ def test_beam_kernels_at_full_vocabulary_and_batch():
         logits = ops.gather_rows(logits, par) + 0.1 * step    # as the caches are re-ordered in the real loop
         sc, ids = ops.beam_topk(logits, beam)
     assert int(cnt[2].item()) == int((fin == 0).sum().item()) and (len_dec >= 1).all() and (len_dec <= 4).all()
+
+
+def test_batch_past_32bit_indexing_gives_the_gradient_of_its_repeated_part():
+    """BASELINE config 5 (long utterances, batch sized for the 288 GB of HBM): 32 utterances of 3000 raw frames repeated
+    8 times - B = 256, T = 1000, 2.56e9 CTC logits (past 32-bit element indices), ~90 GB of activations - must give the
+    losses and the gradient of the 32 (every loss is a mean over utterances; dropout off)."""
+    model, _ = _lut_model(dropout=0.0)
+    host = make_batch(B=32, Traw=3000, V=V, L=40, U=40, Lb=40, bert_dim=768, seed=11, ragged=True)
+    small = {k: torch.from_numpy(v).to(DEV) for k, v in host.items()}
+    a = model.forward_backward(small).clone()
+    ga = model.store.grads.clone()
+    big = {k: v.repeat((8,) + (1,) * (v.dim() - 1)).contiguous() for k, v in small.items()}
+    assert big['feature'].shape[0] * 1000 * V > 2 ** 31
+    b = model.forward_backward(big).clone()
+    gb = model.store.grads
+    assert torch.isfinite(b).all() and torch.allclose(a, b, rtol=2e-3), (a, b)
+    rel = (gb - ga).norm().item() / ga.norm().item()
+    assert rel < 1e-2, rel
+    del big, small, model
+    torch.cuda.empty_cache()
