@@ -197,6 +197,8 @@ def _examples(dir_data, args, _shuffle, fields, epoch_seed=None, verify_crc=True
         for i in range(len(rf)):
             ident = np.array([1], np.int32) if d.withoutid else rf.field(i, 'id', np.int32)
             feature = rf.field(i, 'feature', np.float32).reshape(-1, d.dim_feature)[:cut]
+            if feature.shape[0] == 0:       # nothing to align a label to (the reference drops damaged samples when it writes, :353-355)
+                continue
             yield (ident, feature) + tuple(rf.field(i, key, dt).reshape(shape) for key, dt, shape in fields)
 
 

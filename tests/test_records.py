@@ -206,6 +206,15 @@ def test_train_reader_shuffles_files_per_epoch_and_prefetcher_preserves_order(tm
     assert first != second                                 # ...in a new file order each time
 
 
+def test_reader_skips_utterances_without_frames(tmp_path):
+    rng = np.random.default_rng(8)
+    samples = _samples(6, rng, bert=16)
+    samples[2]['feature'] = np.zeros((0, 4), np.float32)
+    R.save2tfrecord_ctcbert(samples, tmp_path)
+    ids = [int(ex[0][0]) for ex in R.readTFRecord_ctcbert(str(tmp_path), _args('infer'))]
+    assert ids == [0, 1, 3, 4, 5]
+
+
 def test_prefetcher_hands_errors_to_the_consumer(tmp_path):
     def gen():
         yield 1
