@@ -305,3 +305,16 @@ def test_avg_checkpoints_cli(tmp_path):
     assert out.endswith('.npz') and np.array_equal(ck.load_variable(out, 'w'), np.full((2, 3), 4.0, np.float32))
     with pytest.raises(ValueError):
         avg.main(['--checkpoints', 'nope', '--prefix', str(tmp_path) + '/'])
+
+
+def test_run_lut_helpers(tmp_path):
+    """st/bin/run_lut.py host helpers: vocabulary file -> ids (arguments.py:92, first column, line number = id) and the
+    rank sharding of the deterministic batch stream (rank r of N takes batches r, r + N, ...)"""
+    from neurst_amd.st.bin import run_lut
+    (tmp_path / 'vocab.txt').write_text('<pad>\n<unk> 7\n<sos>\n<eos>\nhello 12\n\nworld\n<blk>\n', encoding='utf-8')
+    t2i, i2t = run_lut.load_vocab(str(tmp_path / 'vocab.txt'))
+    assert t2i == {'<pad>': 0, '<unk>': 1, '<sos>': 2, '<eos>': 3, 'hello': 4, 'world': 5, '<blk>': 6} and i2t[5] == 'world'
+    stream = list(range(23))
+    shards = [list(run_lut._Shard(stream, r, 4)) for r in range(4)]
+    assert shards[0] == [0, 4, 8, 12, 16] and shards[3] == [3, 7, 11, 15, 19]     # whole rounds only: every rank takes the same number of steps
+    assert sorted(sum(shards, [])) == list(range(20))
