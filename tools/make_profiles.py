@@ -3,6 +3,7 @@
   profiles/<tag>_bench_lut_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied verbatim)
   profiles/<tag>_hbm_traffic.json             per-kernel HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B),
                                               the gfx950 correction of MI355X_MICROARCH.md 'HBM', from two separate --pmc passes
+  profiles/<tag>_mfma_util.json               per-kernel MfmaUtil (matrix-pipe busy share) from a --pmc MfmaUtil pass, when gpurun_out/<tag>/mfma exists
 Usage: python tools/make_profiles.py r01"""
 import collections
 import csv
@@ -65,6 +66,20 @@ def main(tag):
         out['bytes_per_launch'][label] = round(1000 * (2 * fb + wb))
         out['raw_kernel_names'][label] = {'name': k, 'launches': len(f[k]), 'fetch_kb': round(fb, 1), 'write_kb': round(wb, 1)}
     json.dump(out, open(os.path.join(dst, tag + '_hbm_traffic.json'), 'w'), indent=1)
+    mf = os.path.join(src, 'mfma', 'm_counter_collection.csv')
+    if os.path.exists(mf):            # a fourth pass: --pmc MfmaUtil
+        util, dur = collections.defaultdict(list), collections.defaultdict(list)
+        for r in csv.DictReader(open(mf)):
+            k = gemm_label(r['Kernel_Name']) or r['Kernel_Name'].split('(')[0]
+            util[k].append(float(r['Counter_Value']))
+            dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        kernels = {k: {'launches': len(v), 'mfma_util_mean_percent': round(sum(v) / len(v), 1), 'mfma_util_max_percent': round(max(v), 1),
+                       'avg_us_under_counters': round(sum(dur[k]) / len(v), 1)}
+                   for k, v in sorted(util.items(), key=lambda kv: -sum(dur[kv[0]])) if max(v) > 0}
+        json.dump({'source': 'rocprofv3 --pmc MfmaUtil -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams',
+                   'formula': 'MfmaUtil = 100 * sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM): share of the cycles a kernel was on the GPU in '
+                              'which a SIMD had its matrix pipe busy, at the clock the chip held during that kernel',
+                   'kernels': kernels}, open(os.path.join(dst, tag + '_mfma_util.json'), 'w'), indent=1)
     print('wrote', os.listdir(dst))
 
 
