@@ -375,3 +375,33 @@ def test_bucketed_allreduce_plumbing_over_rccl_one_rank(tmp_path):
     p = subprocess.run([sys.executable, str(script), str(29600 + os.getpid() % 2000)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
     out = p.stdout.decode()
     assert p.returncode == 0 and 'rccl one-rank ok' in out, out[-3000:]
+
+
+def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
+    """bench.py's contract: stdout is ONE JSON line (library banners go to stderr) carrying the driver's keys and the
+    roofline object; under torch.distributed.run with one rank the same holds (RCCL prints a version banner to stdout)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = ge.ROOT
+    base = [os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
+    runs = [[sys.executable] + base,
+            [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+             '--master-port', '29713'] + base]
+    for cmd in runs:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.split('\n') if l.strip()]
+        assert len(lines) == 1, out.stdout[:2000]
+        d = json.loads(lines[0])
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                  'data', 'config', 'roofline'):
+            assert k in d, k
+        assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['vs_baseline'] is None
+        assert d['higher_is_better'] is True and d['dtype'] == 'bf16' and 'workload' in d['config'] and 'model' not in d['config']
+        r = d['roofline']
+        for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert k in r, k
+        assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+        assert abs(d['value'] - 32 * 500 / (d['ms_per_step'] / 1e3)) < 1e-3 * d['value']
