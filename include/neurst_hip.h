@@ -112,6 +112,14 @@ int neurst_mha_fwd_train(const void* q, const void* k, const void* v, void* o, f
                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
                          int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
+/* The same decisions ahead of the forward: neurst_mha_keep_bits fills keep_bits from (key, shape) alone - it can run on
+ * another stream while the projection in front of the attention still works - and neurst_mha_fwd_pregen is
+ * neurst_mha_fwd_train reading them instead of hashing (bit-identical outputs). */
+int neurst_mha_keep_bits(uint16_t* keep_bits, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float rate, uint32_t key, void* stream);
+int neurst_mha_fwd_pregen(const void* q, const void* k, const void* v, void* o, float* lse, const uint16_t* keep_bits,
+                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                          int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                          int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
 int neurst_mha_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                          const float* lse, const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv,
                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,

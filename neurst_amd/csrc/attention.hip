@@ -177,6 +177,7 @@ struct AttnArgs {
   // written by the forward, read back by both backward kernels instead of re-hashing 16 indices per thread and tile
   uint16_t* keep_bits;
   int nqt, nkt;
+  int keep_bits_ready;   // forward: keep_bits already holds the decisions (neurst_mha_keep_bits): load them instead of hashing
 };
 
 // XCD-aware block placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order, so the tiles that share one
@@ -314,8 +315,13 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
     const float alpha = (m_run == -INFINITY) ? 0.f : SM<T>::ex(m_run - mn);
     m_run = mn;
     float lsum = 0.f;
-    const uint32_t kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
-    if (a.keep_bits && a.thr) a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid] = (uint16_t)kmask;
+    uint32_t kmask;
+    if (a.keep_bits_ready) {
+      kmask = a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid];
+    } else {
+      kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+      if (a.keep_bits && a.thr) a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid] = (uint16_t)kmask;
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -659,11 +665,38 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
     else DISPATCH_ONE(T, KERNEL, SMEMFN, GRID, NAME, 192);                                               \
   } while (0)
 
+// The forward's dropout decisions ahead of time: same grid, same block placement and same lane -> weight assignment as
+// mha_fwd_kernel, nothing but the hash.  Depends on the key and the shape only, so it can run on another stream while
+// the projection GEMM in front of the attention still works (the vector pipes idle under a GEMM).
+__global__ void __launch_bounds__(256) mha_keep_bits_kernel(AttnArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
+  const BlockId bid = remap_block();
+  const int64_t bh = bid.z * a.H + bid.y, qi = bid.x * 64 + w * 16 + (lane & 15);
+  const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
+  for (int64_t kv0 = 0; kv0 < a.Tk; kv0 += 64)
+    a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid] = (uint16_t)keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+}
+
+extern "C" int neurst_mha_keep_bits(uint16_t* keep_bits, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float rate, uint32_t key, void* stream) {
+  NEURST_CHECK_ARG(keep_bits && ((uintptr_t)keep_bits & 3) == 0, "mha_keep_bits: keep_bits must be a 4-byte aligned buffer");
+  NEURST_CHECK_ARG(rate > 0.f && rate < 1.f, "mha_keep_bits: dropout rate must be in (0, 1)");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.keep_bits = keep_bits;
+  a.ldq = a.ldk = a.ldv = a.ldo = 1;
+  int rc = fill_args(a, B, H, Tq, Tk, 1, NEURST_MASK_NONE, nullptr, rate, key, NEURST_BF16);
+  if (rc) return rc;
+  dim3 grid((unsigned)cdiv64(Tq, 64), (unsigned)H, (unsigned)B);
+  mha_keep_bits_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
+  NEURST_CHECK_LAUNCH("mha_keep_bits");
+  return NEURST_OK;
+}
+
 extern "C" int64_t neurst_mha_keep_bits_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk) {
   return B * H * cdiv64(Tq, 64) * cdiv64(Tk, 64) * 256 * (int64_t)sizeof(uint16_t);
 }
 
-static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits, int64_t ldq, int64_t ldk,
+static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits, int keep_bits_ready, int64_t ldq, int64_t ldk,
                         int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t B, int64_t H,
                         int64_t Tq, int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key,
                         int dtype, void* stream) {
@@ -672,6 +705,7 @@ static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, fl
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.keep_bits = keep_bits;
+  a.keep_bits_ready = keep_bits_ready;
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
   int rc = fill_args(a, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype);
@@ -691,19 +725,26 @@ extern "C" int neurst_mha_fwd_strided(const void* q, const void* k, const void* 
                                       int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bsv, int64_t bso, int64_t B, int64_t H,
                                       int64_t Tq, int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key,
                                       int dtype, void* stream) {
-  return mha_fwd_impl(q, k, v, o, lse, nullptr, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype, stream);
+  return mha_fwd_impl(q, k, v, o, lse, nullptr, 0, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype, stream);
 }
 extern "C" int neurst_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t ldq, int64_t ldk, int64_t ldv,
                               int64_t ldo, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh, int mask_mode,
                               const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream) {
-  return mha_fwd_impl(q, k, v, o, lse, nullptr, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
+  return mha_fwd_impl(q, k, v, o, lse, nullptr, 0, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
                       len_k, rate, key, dtype, stream);
 }
 extern "C" int neurst_mha_fwd_train(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits, int64_t ldq,
                                     int64_t ldk, int64_t ldv, int64_t ldo, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
                                     int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream) {
-  return mha_fwd_impl(q, k, v, o, lse, keep_bits, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
+  return mha_fwd_impl(q, k, v, o, lse, keep_bits, 0, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq, Tk, dh, mask_mode,
                       len_k, rate, key, dtype, stream);
+}
+extern "C" int neurst_mha_fwd_pregen(const void* q, const void* k, const void* v, void* o, float* lse, const uint16_t* keep_bits, int64_t ldq,
+                                     int64_t ldk, int64_t ldv, int64_t ldo, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                                     int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream) {
+  NEURST_CHECK_ARG(keep_bits && rate > 0.f, "mha_fwd_pregen: needs the decisions of neurst_mha_keep_bits and a dropout rate > 0");
+  return mha_fwd_impl(q, k, v, o, lse, const_cast<uint16_t*>(keep_bits), 1, ldq, ldk, ldv, ldo, Tq * ldq, Tk * ldk, Tk * ldv, Tq * ldo, B, H, Tq,
+                      Tk, dh, mask_mode, len_k, rate, key, dtype, stream);
 }
 
 extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,

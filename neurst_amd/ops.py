@@ -222,10 +222,22 @@ def pick_split_k(M, N, K, n_cu=256):
 
 
 # ---- attention -------------------------------------------------------------------------
+def mha_keep_bits(B, H, Tq, Tk, rate, key, device):
+    """the attention-dropout decisions of one layer from (key, shape) alone, for mha_fwd(..., keep_bits=<this tensor>)"""
+    kb = torch.empty(_C.neurst_mha_keep_bits_bytes(B, H, Tq, Tk) // 2, dtype=torch.int16, device=device)
+    _chk(_C.neurst_mha_keep_bits(_p(kb), B, H, Tq, Tk, rate, key, _s()), 'mha_keep_bits')
+    return kb
+
+
 def mha_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, keep_bits=False):
-    """keep_bits=True (training with dropout): also returns the stored dropout decisions for mha_bwd."""
+    """keep_bits=True (training with dropout): also returns the stored dropout decisions for mha_bwd; keep_bits=<tensor of
+    mha_keep_bits>: the decisions were generated ahead, the forward loads them."""
     o = torch.empty((B, Tq, H * dh), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+    if isinstance(keep_bits, torch.Tensor):
+        _chk(_C.neurst_mha_fwd_pregen(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(keep_bits), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode,
+                                       _p(len_k), rate, key, dt_of(q), _s()), 'mha_fwd_pregen')
+        return o, lse, keep_bits
     if keep_bits:
         kb = torch.empty(_C.neurst_mha_keep_bits_bytes(B, H, Tq, Tk) // 2, dtype=torch.int16, device=q.device) if rate > 0 else None
         _chk(_C.neurst_mha_fwd_train(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(kb), ldq, ldk, ldv, H * dh, B, H, Tq, Tk, dh, mask_mode,

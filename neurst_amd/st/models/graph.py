@@ -273,6 +273,23 @@ class Graph:
             self.wgrad_stream = torch.cuda.Stream(device=device)
         return self.wgrad_stream
 
+    def run_ahead(self, launch, device):
+        """Runs `launch()` (kernels that read no activations, e.g. the dropout decisions of the next attention) on the
+        weight-gradient stream - idle during forward - behind everything enqueued so far, and returns (its result, an
+        event the consumer's stream has to wait for).  The result is allocated from the main stream's pool as usual."""
+        if self.wgrad_stream is None:
+            self.wgrad_stream = torch.cuda.Stream(device=device)
+        side = self.wgrad_stream
+        side.wait_stream(torch.cuda.current_stream())      # the block handed out may still be read by earlier main-stream kernels
+        ops.set_stream(side)
+        try:
+            out = launch()
+        finally:
+            ops.set_stream(None)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return out, ev
+
     def run_on_side(self, side, launch, *read_tensors):
         """Enqueue `launch()` (kernels that allocate nothing and read `read_tensors`) on `side`, after everything the
         current stream holds so far.  The tensors stay referenced until join_side_streams, so the caching allocator

@@ -37,6 +37,10 @@ def _wgrad(dy2, x2, param, layout, bias=None):
 # off by default: measured on LUT config 2 the third column sum makes ln_bwd (main stream) slower by more than the operand
 # sum costs the weight-gradient GEMMs (second stream): 16.49 ms per step with it, 16.32 without
 _FUSE_BIAS_GRAD = os.environ.get('NEURST_FUSE_BIAS_GRAD', '0') != '0'
+# attention-dropout decisions hashed ahead on the second stream: off by default - measured 16.43 against 16.32 ms per step (the extra
+# launch, its two stream hand-offs and the share of the chip it takes from the projection GEMM cost more than the hash saves)
+_PREGEN_KEEP_BITS = os.environ.get('NEURST_PREGEN_KEEP_BITS', '0') != '0'
+_PREGEN_MIN_WEIGHTS = 1 << 22                                                  # not for decoder-size attention: one more launch costs more than it saves
 
 
 class BiasGradHook:
@@ -176,6 +180,14 @@ def multihead_attention(query_antecedent, memory_antecedent, bias, total_key_dep
     mode = bias.mode if bias is not None else ops.MASK_NONE
     lens = bias.lens if bias is not None else None
     rate, key = g.rate(dropout_rate), g.key(site)
+    tape = g.tape
+    Tk_ = Tq if memory_antecedent is None else memory_antecedent.shape[1]
+    ahead = None
+    if (tape is not None and rate > 0 and _PREGEN_KEEP_BITS and g.side_streams and query_antecedent.is_cuda
+            and B * H * Tq * Tk_ >= _PREGEN_MIN_WEIGHTS):
+        # the dropout decisions depend on (key, shape) only: hash them on the second stream while the projection GEMM(s)
+        # below keep the matrix pipes busy; the forward then loads them like the backward does
+        ahead = g.run_ahead(lambda: ops.mha_keep_bits(B, H, Tq, Tk_, rate, key, query_antecedent.device), query_antecedent.device)
     with (g.variable_scope(name) if name else g.default_scope('multihead_attention')):
         if memory_antecedent is None:
             combined = dense(query_antecedent, 3 * d, name='qkv_transform')
@@ -192,9 +204,12 @@ def multihead_attention(query_antecedent, memory_antecedent, bias, total_key_dep
             k = (kvbuf, 0, 2 * d)
             v = (kvbuf, d, 2 * d)
         view = lambda t: t[0].view(-1)[t[1]:]       # pointer to the first element of the (strided) operand
-        tape = g.tape
         if tape is not None:   # training: keep the dropout decisions for backward (the TF graph keeps the mask tensor)
-            x, lse, kb = ops.mha_fwd(view(q), view(k), view(v), q[2], k[2], v[2], B, H, Tq, Tk, dh, mode, lens, rate, key, keep_bits=True)
+            pre = True
+            if ahead is not None:
+                pre, ready = ahead
+                torch.cuda.current_stream().wait_event(ready)
+            x, lse, kb = ops.mha_fwd(view(q), view(k), view(v), q[2], k[2], v[2], B, H, Tq, Tk, dh, mode, lens, rate, key, keep_bits=pre)
         else:
             x, lse = ops.mha_fwd(view(q), view(k), view(v), q[2], k[2], v[2], B, H, Tq, Tk, dh, mode, lens, rate, key)
             kb = None

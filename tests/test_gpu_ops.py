@@ -558,3 +558,25 @@ def test_layernorm_bwd_bias_gradient_output(rows, C, rate, dtype):
     want = 0.5 + dy.double().sum(0)
     tol = 1e-4 if dtype == torch.float32 else 2e-2 * max(1.0, float(rows) ** 0.5 / 8)      # bf16: dy is rounded after the fp32 sum was taken
     assert (dbias.double() - want).abs().max().item() < tol * max(1.0, want.abs().max().item()), (dbias.double() - want).abs().max().item()
+
+
+@pytest.mark.parametrize('B,H,Tq,Tk,dh,mode,dtype', [(2, 2, 70, 70, 16, 'keypad', torch.float32), (3, 8, 500, 500, 96, 'keypad', torch.bfloat16),
+                                                     (2, 4, 40, 130, 96, 'keypad', torch.bfloat16), (2, 2, 100, 100, 32, 'causal', torch.float32)])
+def test_attention_forward_with_decisions_generated_ahead(B, H, Tq, Tk, dh, mode, dtype):
+    """neurst_mha_keep_bits + neurst_mha_fwd_pregen against neurst_mha_fwd_train: the same stored decisions (on every tile
+    the forward visits), bit-identical outputs and statistics"""
+    d = H * dh
+    g = torch.Generator(device='cpu').manual_seed(B * Tq)
+    q = (torch.randn(B, Tq, d, generator=g) * 0.5).to(DEV).to(dtype)
+    kv = (torch.randn(B, Tk, 2 * d, generator=g) * 0.5).to(DEV).to(dtype)
+    lens = torch.tensor([Tk] + [max(1, Tk - 17 * (i + 1)) for i in range(B - 1)], dtype=torch.int32, device=DEV)
+    mm = ops.MASK_KEYPAD if mode == 'keypad' else ops.MASK_CAUSAL
+    ln = lens if mode == 'keypad' else None
+    kf = kv.view(-1)
+    o1, lse1, kb1 = ops.mha_fwd(q.view(-1), kf, kf[d:], d, 2 * d, 2 * d, B, H, Tq, Tk, dh, mm, ln, 0.1, 4242, keep_bits=True)
+    kb = ops.mha_keep_bits(B, H, Tq, Tk, 0.1, 4242, DEV)
+    o2, lse2, kb2 = ops.mha_fwd(q.view(-1), kf, kf[d:], d, 2 * d, 2 * d, B, H, Tq, Tk, dh, mm, ln, 0.1, 4242, keep_bits=kb)
+    assert kb2 is kb and torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    if mode == 'keypad':        # with full lengths the forward visits (and stores) every tile: the buffers agree entirely
+        o3, _, kb3 = ops.mha_fwd(q.view(-1), kf, kf[d:], d, 2 * d, 2 * d, B, H, Tq, Tk, dh, ops.MASK_NONE, None, 0.1, 4242, keep_bits=True)
+        assert torch.equal(kb3, kb)
