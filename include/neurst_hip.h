@@ -147,6 +147,19 @@ int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z, const floa
                                      int64_t rows, int64_t C, float rate, uint32_t key,
                                      const int32_t* lens, int64_t T, int dtype, void* stream);
 
+/* Allocation-free variant of neurst_dropout_add_layernorm_bwd.  NO counterpart in the reference: it exists for callers
+ * that cannot allocate device memory - code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc - and therefore cannot bring the `partial` workspace of the deterministic two-pass reduction.  The block
+ * partials live in a 4 MiB (1 Mi floats) array inside the library, one copy per GPU, held until the process ends; the
+ * call is rejected (NEURST_E_INVALID) when 2 * neurst_layernorm_bwd_blocks(rows) * C exceeds 1 Mi floats (e.g. C > 2048 at
+ * 256 blocks).  Same arguments (minus `partial`) and bit-identical results as the call above with a workspace.  It
+ * calls no hipMalloc / hipFree.  All calls on one GPU share the array: calls that overlap on one GPU (two streams) race. */
+int neurst_dropout_add_layernorm_bwd_noalloc(const void* dout, const void* z, const float* gamma,
+                                             const float* mean, const float* rstd, void* dz, void* dy,
+                                             float* dgamma, float* dbeta, float* dbias,
+                                             int64_t rows, int64_t C, float rate, uint32_t key,
+                                             const int32_t* lens, int64_t T, int dtype, void* stream);
+
 /* gradient accumulation helper (a tensor consumed twice): dst += src, same dtype. */
 int neurst_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream);
 

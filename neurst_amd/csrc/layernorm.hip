@@ -442,3 +442,56 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   }
   return NEURST_OK;
 }
+
+// ---------------------------------------------------------------- allocation-free variant (no reference counterpart)
+// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it):
+// the deterministic two-pass column reduction of the backward above, with its [2][nblk][C] fp32 block partials in a
+// file-scope device array instead of a caller workspace.  Every GPU holds its own copy of the array (4 MiB, until the
+// process ends) at its own address: the address is looked up once per device with hipGetSymbolAddress and handed to the
+// kernels as an ordinary pointer - the array's name is never used as an address in host code.  Every block slot that the
+// reduction reads is written by the first pass of the same call, so nothing has to be cleared between calls; two calls
+// that overlap on one GPU (different streams) share the array and race.
+constexpr int64_t LN_SCRATCH_FLOATS = 1 << 20;                      // 4 MiB: e.g. 512 blocks x 2 x 1024 columns
+static __device__ __align__(256) float scratch[LN_SCRATCH_FLOATS];
+constexpr int LN_MAX_DEVICES = 64;
+static float* g_scratch_ptr[LN_MAX_DEVICES];                        // per device, filled on that device's first call
+#include <mutex>
+static std::mutex g_scratch_mu;
+
+static int ln_scratch_for_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= LN_MAX_DEVICES) {
+    neurst_set_error("layernorm_bwd_noalloc: cannot identify the current device (%s)", hipGetErrorString(e));
+    return NEURST_E_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      neurst_set_error("layernorm_bwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return NEURST_E_LAUNCH;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return NEURST_OK;
+}
+
+extern "C" int neurst_dropout_add_layernorm_bwd_noalloc(const void* dout, const void* z, const float* gamma, const float* mean,
+                                                        const float* rstd, void* dz, void* dy, float* dgamma, float* dbeta,
+                                                        float* dbias, int64_t rows, int64_t C, float rate, uint32_t key,
+                                                        const int32_t* lens, int64_t T, int dtype, void* stream) {
+  NEURST_CHECK_ARG(rows > 0 && C > 0, "layernorm_bwd_noalloc: bad shape");
+  const int64_t need = 2 * neurst_layernorm_bwd_blocks(rows) * C;
+  NEURST_CHECK_ARG(need <= LN_SCRATCH_FLOATS,
+                   "layernorm_bwd_noalloc: rows=%ld x C=%ld needs %ld floats of block partials, the built-in scratch holds %ld "
+                   "(use neurst_dropout_add_layernorm_bwd with a caller workspace)",
+                   (long)rows, (long)C, (long)need, (long)LN_SCRATCH_FLOATS);
+  float* ptr = nullptr;
+  const int rc = ln_scratch_for_current_device(&ptr);
+  if (rc != NEURST_OK) return rc;
+  return neurst_dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dz, dy, dgamma, dbeta, ptr, dbias, rows, C, rate, key, lens, T,
+                                          dtype, stream);
+}
