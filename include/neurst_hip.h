@@ -32,6 +32,11 @@ enum { NEURST_MASK_NONE = 0, NEURST_MASK_KEYPAD = 1, NEURST_MASK_CAUSAL = 2 };
 const char* neurst_last_error(void);
 int neurst_abi_version(void);
 
+/* Kernel-selection switches for tests and A/B timing (no reference counterpart; defaults come from the environment
+ * variables of the same upper-case name with the NEURST_ prefix): "gemm256" 1/0 = large bf16 GEMMs may use the
+ * 256 x 256-tile kernel; "gemm256_min_tiles" = smallest number of 256 x 256 tiles for which it is chosen (128). */
+int neurst_set_option(const char* name, int value);
+
 /* a1: splice(left=0,right=num_context) + down_sample(rate)
  * st/tools/tftools/tfAudioTools.py:69-98, st/tools/tftools/tfRecord.py:827-845.
  * x [B,Traw,F] fp32 -> out [B,ceil(Traw/rate),F*(num_context+1)] (out_dtype);

@@ -608,6 +608,17 @@ extern "C" int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, fl
   return NEURST_OK;
 }
 
+// run-time switches (tests and A/B timing run both kernels in one process); initialised from the environment
+static int g_opt_gemm256 = [] { const char* e = getenv("NEURST_GEMM256"); return e ? atoi(e) : 1; }();
+int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TILES"); return e ? atoi(e) : 128; }();
+static bool use_gemm256() { return g_opt_gemm256 != 0; }
+extern "C" int neurst_set_option(const char* name, int value) {
+  NEURST_CHECK_ARG(name, "set_option: null name");
+  if (!strcmp(name, "gemm256")) g_opt_gemm256 = value;
+  else if (!strcmp(name, "gemm256_min_tiles")) g_opt_gemm256_min_tiles = value;
+  else { neurst_set_error("set_option: unknown option '%s'", name); return NEURST_E_INVALID; }
+  return NEURST_OK;
+}
 extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bias, const void* relu_src, int64_t M,
                                     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
                                     int ab_dtype, int c_dtype, int relu, int accumulate, int split_k, void* stream) {
@@ -628,6 +639,11 @@ extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const
   if (ab_dtype == NEURST_BF16) {
     // FAST: direct-to-LDS staging needs 16-byte aligned rows and whole 8-element chunks along every contiguous axis
     const bool fast = g.a_aligned && g.b_aligned && K % 8 == 0 && (!trans_a || M % 8 == 0) && (trans_b || N % 8 == 0);
+    if (fast && use_gemm256() && neurst_gemm256_eligible(g, trans_a, trans_b)) {
+      neurst_gemm256_launch(g, trans_a, trans_b, c_dtype, s);
+      NEURST_CHECK_LAUNCH("gemm256");
+      return NEURST_OK;
+    }
     if (c_dtype == NEURST_BF16) { if (fast) launch_gemm<bf16_t, bf16_t, true>(g, trans_a, trans_b, s); else launch_gemm<bf16_t, bf16_t, false>(g, trans_a, trans_b, s); }
     else { if (fast) launch_gemm<bf16_t, float, true>(g, trans_a, trans_b, s); else launch_gemm<bf16_t, float, false>(g, trans_a, trans_b, s); }
   } else {

@@ -1,0 +1,364 @@
+// K3, large grids: C[M,N] = op(A) . op(B) (+bias)(relu)(relu-grad gate)(+C) for bf16 operands on a 256 x 256 output
+// tile per workgroup - the GEMMs with M = B*T rows of `dense` (st/models/tools/utils.py:367-398), tf.layers.dense and
+// their data gradients, where the 128 x 128 kernels of gemm.hip reach 25-35 % of the matrix peak.
+//
+// Structure (cdna_hip_programming.md section 5, "The 256^2 8-phase template", rebuilt here as a ring of operand PIECES):
+//  * 8 waves (2 along M x 4 along N), wave tile 128 x 64 = 8 x 4 MFMA tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator
+//    registers), K-tile 64.  One workgroup per CU (144 KiB LDS), persistent: it walks its output tiles and keeps the
+//    operand stream running across tile seams (the next tile's first pieces are in flight during the epilogue).
+//  * A K-tile is cut into 4 pieces of 16 KiB, each read from LDS in exactly ONE phase:
+//        piece 0: the first 32 of every wave column's 64 B-columns   (read in phase 0, kept in registers until phase 3)
+//        piece 1: the first 64 of every wave row's 128 A-rows         (read in phase 0)
+//        piece 2: the other 32 B-columns                              (read in phase 1)
+//        piece 3: the other 64 A-rows                                 (read in phase 2)
+//    phase 0: C[m0][n0] += A0.B0, phase 1: C[m0][n1] += A0.B1, phase 2: C[m1][n1] += A1.B1, phase 3: C[m1][n0] += A1.B0
+//    (16 MFMAs per wave and phase).  Pieces are numbered s = 4 * (K-tile) + piece and live in LDS slot s mod 8.
+//  * Every phase issues ONE piece, 6 pieces ahead of the one numbered like the phase (2 buffer_load ... lds per thread),
+//    and waits with a COUNTED vmcnt(8) for the pieces the next phase reads: four pieces (64 KiB per CU) stay in flight
+//    across the barriers.  Slot reuse: piece s+8 is issued in phase s+2, at least two phases after the last read of
+//    piece s; a piece is read one phase after the wait + barrier that retires it (both groups of waves, see below).
+//  * The waves of wave-row 1 run one barrier behind those of wave-row 0 (waves w and w+4 share a SIMD): while one of the
+//    two computes its 16 MFMAs the other reads LDS and issues loads, two barriers per phase.
+//  * Operands arrive by buffer_load ... lds with the XOR swizzle on the SOURCE side (rule 21); rows / columns beyond the
+//    operand's end read as zero through the descriptor's range check, so there is no clamping in the loop.  k-strided
+//    operands ([K][rows] in memory: the weight of a data gradient, both operands of a weight gradient) keep their memory
+//    layout in LDS and are read with the transposing ds_read_b64_tr_b16.
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_tiles.h"
+
+namespace t2 {
+
+constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+constexpr int PIECE = 128 * 64;                                // elements of one piece (16 KiB)
+constexpr int RING_BYTES = 8 * PIECE * 2;                      // 128 KiB
+constexpr int EPI_BYTES = 8 * 16 * PEPI_LD * 4;                // one 16 x 32 fp32 staging tile per wave
+constexpr int OOB = 0x7ffffff0;                                // byte offset beyond any descriptor's range
+constexpr int64_t MAX_RECORDS = 0x7fff0000;
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef __attribute__((address_space(3))) char* lds_cp;
+
+// raw buffer descriptor (stride 0, 32-bit records in bytes, gfx9 raw-buffer flags): built by hand so that it can be an
+// SGPR operand of the asm statement below
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned records) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, records, 0x00020000u};
+}
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes from rsrc + voff (per lane) to LDS bytes lds_addr .. lds_addr + 1023
+// (wave-uniform, lane-linear).  In inline asm on purpose: hipcc then neither counts it in its own vmcnt bookkeeping nor
+// orders LDS reads behind it - with the builtin it drains the whole ring (vmcnt(0)) at the head of every K-loop iteration.
+// Completion is counted by hand (the vmcnt(8) waits of the K loop).  M0 is saved and restored inside the statement
+// (cdna_hip_programming.md 5.7); the s_nop covers M0 -> LDS-DMA and a freshly written descriptor register.
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, int voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+typedef Stager<bf16_t, false, 64, 128> SK;                     // K-contiguous piece: [128 rows][64 k], 128-byte rows
+typedef Stager<bf16_t, true, 64> ST;                           // k-strided piece:    [64 k][128 columns], 256-byte rows
+
+// Byte offset, relative to the operand's (tile, K-tile) origin, of the 16-byte chunk this thread fetches in issue i (0, 1)
+// of the piece holding half `sub` (0, 1) of every wave row's A rows (IS_A) or of every wave column's B columns.
+template <bool KSTRIDED, bool IS_A>
+__device__ __forceinline__ int piece_voff(int tid, int i, int sub, int64_t ld) {
+  if constexpr (!KSTRIDED) {
+    const int r = i * 64 + (tid >> 3);                         // row of the LDS image
+    const int c = (tid & 7) ^ (r & 7);                         // source chunk that belongs at LDS chunk position tid & 7
+    const int row = IS_A ? (r >> 6) * 128 + sub * 64 + (r & 63) : (r >> 5) * 64 + sub * 32 + (r & 31);
+    return (int)(row * ld * 2) + c * 16;
+  } else {
+    const int P = i * 512 + tid;
+    const int r = P >> 4;                                      // k row of the LDS image
+    const int c = (P & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    const int col = IS_A ? (c >> 3) * 128 + sub * 64 + (c & 7) * 8 : (c >> 2) * 64 + sub * 32 + (c & 3) * 8;
+    return (int)(r * ld * 2) + col * 2;
+  }
+}
+
+struct Args {
+  GemmArgs g;
+  int nk;                 // K-tiles per output tile
+  int rounds_total;       // unused (kept for debugging)
+};
+
+template <bool KSTRIDED>
+__device__ __forceinline__ bf16x8 frag(const bf16_t* __restrict__ piece, int first, int ks, int lane) {
+  if constexpr (!KSTRIDED) return SK::frag(piece, first, ks, lane);
+  else return ST::frag(piece, first, ks, lane);
+}
+
+template <typename TC, bool TA, bool TBK>
+__global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
+  constexpr bool AKS = TA, BKS = !TBK;                         // operand is k-strided in memory
+  const GemmArgs& g = args.g;
+  __shared__ __attribute__((aligned(16))) char smem[RING_BYTES + EPI_BYTES];   // ONE LDS object
+  bf16_t* const ring = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  float* const Cs = reinterpret_cast<float*>(smem + RING_BYTES) + wave * 16 * PEPI_LD;
+  const bf16_t* const A = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* const B = reinterpret_cast<const bf16_t*>(g.B);
+  const int nk = args.nk;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_cp)smem;      // LDS byte address of the ring
+
+  // ---- static tile schedule (as gemm_persist_kernel): in every full round each XCD's workgroups take a contiguous run of
+  // the grouped tile order, the last partial round is dealt evenly to the XCDs
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int G = gridDim.x, per_xcd = G >> 3;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
+  const int rq = rem >> 3, rr8 = rem & 7;
+  const int rem_beg = full_rounds * G + (xcd < rr8 ? xcd * (rq + 1) : rr8 * (rq + 1) + (xcd - rr8) * rq);
+  const int rem_cnt = xcd < rr8 ? rq + 1 : rq;
+  auto tile_at = [&](int r) -> int {
+    if (r < full_rounds) return r * G + xcd * per_xcd + loc;
+    if (r == full_rounds && loc < rem_cnt) return rem_beg + loc;
+    return -1;
+  };
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  auto coords = [&](int t, int64_t& m0, int64_t& n0) {
+    const int group = t / per_group, first_m = group * GM;
+    const int gsz = g.tiles_m - first_m < GM ? g.tiles_m - first_m : GM;
+    m0 = (int64_t)(first_m + (t % per_group) % gsz) * BM;
+    n0 = (int64_t)((t % per_group) / gsz) * BN;
+  };
+  if (tile_at(0) < 0) return;                                  // whole workgroup: nothing to do
+
+  // ---- per-thread source offsets of the four piece kinds
+  int voA[2][2], voB[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      voA[sub][i] = piece_voff<AKS, true>(tid, i, sub, g.lda);
+      voB[sub][i] = piece_voff<BKS, false>(tid, i, sub, g.ldb);
+    }
+  const int kc8 = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;          // first k of this thread's chunk in a K-contiguous piece
+
+  // ---- load cursor: runs 6 pieces ahead of the compute cursor, across output tiles
+  int l_round = 0, l_tile = tile_at(0), l_kt = 0;
+  int64_t l_m0 = 0, l_n0 = 0;
+  coords(l_tile, l_m0, l_n0);
+  u32x4 rsA, rsB;
+  int l_krem = 0;
+  auto set_rsrc = [&]() __attribute__((always_inline)) {
+    if (l_tile < 0) {                                          // past the last tile: every load is out of range (zeros, no traffic)
+      rsA = make_rsrc(A, 0);
+      rsB = make_rsrc(B, 0);
+      l_krem = BK;
+      return;
+    }
+    const int64_t k0 = (int64_t)l_kt * BK;
+    if (k0 >= g.K) {                                           // the all-zero K-tile that pads an odd count
+      rsA = make_rsrc(A, 0);
+      rsB = make_rsrc(B, 0);
+      l_krem = BK;
+      return;
+    }
+    // first element of this (tile, K-tile) and one past the operand's last element
+    const int64_t a_org = AKS ? k0 * g.lda + l_m0 : l_m0 * g.lda + k0;
+    const int64_t a_end = AKS ? (g.K - 1) * g.lda + g.M : (g.M - 1) * g.lda + g.K;
+    const int64_t b_org = BKS ? k0 * g.ldb + l_n0 : l_n0 * g.ldb + k0;
+    const int64_t b_end = BKS ? (g.K - 1) * g.ldb + g.N : (g.N - 1) * g.ldb + g.K;
+    int64_t ra = (a_end - a_org) * 2, rb = (b_end - b_org) * 2;
+    ra = ra < 0 ? 0 : (ra > MAX_RECORDS ? MAX_RECORDS : ra);
+    rb = rb < 0 ? 0 : (rb > MAX_RECORDS ? MAX_RECORDS : rb);
+    rsA = make_rsrc(A + a_org, (unsigned)ra);
+    rsB = make_rsrc(B + b_org, (unsigned)rb);
+    l_krem = (int)(g.K - k0);
+  };
+  auto advance_k = [&]() __attribute__((always_inline)) {
+    if (l_tile >= 0 && ++l_kt == nk) {
+      l_kt = 0;
+      l_tile = tile_at(++l_round);
+      if (l_tile >= 0) coords(l_tile, l_m0, l_n0);
+    }
+    set_rsrc();
+  };
+  set_rsrc();
+  // piece kind 0: B sub 0, 1: A sub 0, 2: B sub 1, 3: A sub 1 of the cursor's K-tile, into LDS slot `slot`
+  auto issue = [&](int kind, int slot) __attribute__((always_inline)) {
+    const bool isA = kind & 1;
+    const int sub = kind >> 1;
+    const unsigned dst = lds0 + (unsigned)(slot * PIECE + wave * 512) * 2;   // this wave's 1 KiB of each 8 KiB issue
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int vo = isA ? voA[sub][i] : voB[sub][i];
+      // partial last K-tile of a K-contiguous operand: chunks at or beyond K must read as zero (a k-strided operand gets
+      // that from the range check: rows beyond K lie beyond its end)
+      if (l_krem < BK && !(isA ? AKS : BKS)) vo = kc8 < l_krem ? vo : OOB;
+      dma16(isA ? rsA : rsB, dst + i * 8192, vo);
+    }
+  };
+
+  // ---- prologue: pieces 0..5
+  issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+  advance_k();
+  issue(0, 4); issue(1, 5);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // pieces 0 and 1 of this wave have landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();                   // wave row 1 runs one barrier behind wave row 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 acc[8][4];
+  bf16x8 af[4][2], b0[2][2], b1[2][2];
+
+  // one K-tile = 4 phases; PAR = parity of the K-tile's global index (LDS slots 4 PAR .. 4 PAR + 3)
+  auto ktile = [&](auto par_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    const bf16_t* const s0 = ring + (4 * PAR + 0) * PIECE;
+    const bf16_t* const s1 = ring + (4 * PAR + 1) * PIECE;
+    const bf16_t* const s2 = ring + (4 * PAR + 2) * PIECE;
+    const bf16_t* const s3 = ring + (4 * PAR + 3) * PIECE;
+    // ---------------- phase 0
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = frag<BKS>(s0, wc * 32 + ni * 16, ks * 32, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[mi][ks] = frag<AKS>(s1, wr * 64 + mi * 16, ks * 32, lane);
+    issue(2, (4 * PAR + 6) & 7);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b0[ni][ks], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- phase 1
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = frag<BKS>(s2, wc * 32 + ni * 16, ks * 32, lane);
+    issue(3, (4 * PAR + 7) & 7);
+    advance_k();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b1[ni][ks], acc[mi][2 + ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- phase 2
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[mi][ks] = frag<AKS>(s3, wr * 64 + mi * 16, ks * 32, lane);
+    issue(0, 4 * PAR + 0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b1[ni][ks], acc[4 + mi][2 + ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- phase 3
+    issue(1, 4 * PAR + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b0[ni][ks], acc[4 + mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int round = 0;; ++round) {
+    const int tile = tile_at(round);
+    if (tile < 0) break;
+    int64_t m0, n0;
+    coords(tile, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; kt += 2) {                       // nk is even (an odd count is padded with an all-zero K-tile)
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+    }
+    // ---- epilogue of this tile; the next tile's first pieces are already in flight
+    float bcol[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + wc * 64 + j * 16 + (lane & 15);
+        bcol[j] = col < g.N ? g.bias[col] : 0.f;
+      }
+    }
+    // in two halves of 64 rows: the ReLU-gate prefetch of the epilogue then holds 32 registers beside the 128 accumulators
+    persist_epilogue<bf16_t, TC, 4>(g, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), bcol, Cs, m0 + wr * 128, n0 + wc * 64, lane);
+    persist_epilogue<bf16_t, TC, 4>(g, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]), bcol, Cs, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+    // the stores above are younger than the pieces in flight: drain everything, so that the counted waits of the next
+    // tile's first phases again count only pieces
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // pieces issued past the last tile (out of range: no data)
+  if (wr == 0) __builtin_amdgcn_s_barrier();                   // balance the stagger
+}
+
+}  // namespace t2
+
+// The 256 x 256 kernel takes a problem when it is large enough to fill the chip with 256-wide tiles and its operands can be
+// addressed by 32-bit byte offsets from a tile origin.  trans_a: A stored [K][M]; trans_b: B stored [N][K].
+extern int g_opt_gemm256_min_tiles;                          // gemm.hip: neurst_set_option("gemm256_min_tiles", n)
+static int t2_min_tiles() { return g_opt_gemm256_min_tiles; }
+bool neurst_gemm256_eligible(const GemmArgs& g, int trans_a, int trans_b) {
+  if (g.split_k != 1 || g.opsum) return false;
+  if (!g.a_aligned || !g.b_aligned || g.K % 8 || (trans_a && g.M % 8) || (!trans_b && g.N % 8)) return false;
+  const int64_t tm = cdiv64(g.M, t2::BM), tn = cdiv64(g.N, t2::BN);
+  if (tm * tn < t2_min_tiles()) return false;
+  // 32-bit offsets inside one (tile, K-tile) window
+  const int64_t wa = trans_a ? 64 * g.lda + 256 : 256 * g.lda + 64;
+  const int64_t wb = trans_b ? 256 * g.ldb + 64 : 64 * g.ldb + 256;
+  if (wa * 2 >= 0x7fff0000ll || wb * 2 >= 0x7fff0000ll) return false;
+  return true;
+}
+template <typename TC>
+static void launch256(const GemmArgs& g0, int trans_a, int trans_b, hipStream_t s) {
+  t2::Args a;
+  a.g = g0;
+  a.g.tiles_m = (int)cdiv64(g0.M, t2::BM);
+  a.g.tiles_n = (int)cdiv64(g0.N, t2::BN);
+  a.nk = (int)((cdiv64(g0.K, t2::BK) + 1) / 2 * 2);       // even: the K loop runs two K-tiles per iteration
+  a.rounds_total = 0;
+  const int ntiles = a.g.tiles_m * a.g.tiles_n;
+  int grid = ntiles >= 256 ? 256 : (ntiles + 7) / 8 * 8;
+  if (!trans_a && trans_b) t2::gemm256_kernel<TC, false, true><<<grid, t2::NT, 0, s>>>(a);
+  else if (!trans_a && !trans_b) t2::gemm256_kernel<TC, false, false><<<grid, t2::NT, 0, s>>>(a);
+  else if (trans_a && !trans_b) t2::gemm256_kernel<TC, true, false><<<grid, t2::NT, 0, s>>>(a);
+  else t2::gemm256_kernel<TC, true, true><<<grid, t2::NT, 0, s>>>(a);
+}
+void neurst_gemm256_launch(const GemmArgs& g, int trans_a, int trans_b, int c_dtype, hipStream_t s) {
+  if (c_dtype == NEURST_BF16) launch256<bf16_t>(g, trans_a, trans_b, s);
+  else launch256<float>(g, trans_a, trans_b, s);
+}

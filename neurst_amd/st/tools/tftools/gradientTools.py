@@ -13,6 +13,22 @@ import torch.distributed as dist
 _DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
 
 
+class _HostStagedWork:
+    """Handle of a bucket that gloo reduces in pinned host memory: wait() = the host waits for the reduction, then the
+    copy back to the device is enqueued on the communication stream and the current stream is made to wait for it."""
+
+    def __init__(self, work, host, dev, stream):
+        self.work, self.host, self.dev, self.stream = work, host, dev, stream
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            with torch.cuda.stream(self.stream):
+                self.dev.copy_(self.host, non_blocking=True)
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class GradBucketer:
     """Completion tracking of the gradient arena in contiguous buckets.
 
@@ -35,6 +51,15 @@ class GradBucketer:
         self.reduce = self.world > 1 or (bool(os.environ.get('NEURST_FORCE_BUCKETS')) and dist.is_available() and dist.is_initialized())
         self.use_stream = store.grads.is_cuda
         self.comm_stream = comm_stream or (torch.cuda.Stream() if (self.use_stream and self.reduce) else None)
+        # gloo with device tensors (two ranks rehearsing on ONE GPU; RCCL refuses that): gloo's own CUDA path - a pinned
+        # copy per call on pool streams, host threads that synchronise them - hangs on this ROCm stack as soon as a few
+        # asynchronous device-tensor all-reduces are in flight, with no code of this package involved
+        # (tools/exp/gloo_cuda_check.py: one at a time passes, 2 or 4 or 60 in flight hang, 8 passed once; staged by hand
+        # passes).  So gloo only ever sees HOST tensors here: a bucket is copied to pinned memory on the communication
+        # stream, reduced there, and copied back before anything waits for its handle.  The host waits for the copy, so
+        # this mode has no overlap to measure - it is for checking the N > 1 arithmetic and call order on one GPU.
+        self.host_stage = bool(self.reduce and self.use_stream and dist.get_backend(group) == 'gloo')
+        self.host_buf = None
         self.apply_fn = None
         self.apply_in_backward = True    # False: buckets are only updated in finish(), in launch order, behind their all-reduce
         elems = max(bucket_bytes // 4, 1)
@@ -116,7 +141,16 @@ class GradBucketer:
             print('[bucketer r%d] launch bucket %d of %d' % (dist.get_rank(), b, len(self.bounds)), flush=True)
         s, e = self.bounds[b]
         view = self.store.grads[s:e]
-        if self.comm_stream is not None:
+        if self.host_stage:
+            if self.host_buf is None:
+                self.host_buf = torch.empty(self.store.total, dtype=self.store.grads.dtype).pin_memory()
+            self._wait_for_producers(self.comm_stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.host_buf[s:e].copy_(view, non_blocking=True)
+            self.comm_stream.synchronize()
+            self.handles[b] = _HostStagedWork(dist.all_reduce(self.host_buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                                              self.host_buf[s:e], view, self.comm_stream)
+        elif self.comm_stream is not None:
             self._wait_for_producers(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
                 self.handles[b] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -377,6 +377,96 @@ def test_bucketed_allreduce_plumbing_over_rccl_one_rank(tmp_path):
     assert p.returncode == 0 and 'rccl one-rank ok' in out, out[-3000:]
 
 
+TWO_RANK_WORKER = r"""
+import os, sys, faulthandler
+faulthandler.dump_traceback_later(100, exit=True)
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import __graft_entry__ as ge
+from neurst_amd.synthetic import make_batch
+from neurst_amd.st.models.TransformerTPE import GlobalStep
+rank, port, outdir, loss_type = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4]
+torch.cuda.set_device(0)
+# two ranks on ONE GPU: RCCL refuses that, so the process group is gloo; the bucketer then stages every bucket through
+# pinned host memory (gradientTools.GradBucketer.host_stage)
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + port, rank=rank, world_size=2)
+args = ge.tiny_args(loss_type=loss_type, compute_dtype='fp32', shrink=(loss_type == 'ce_ctc'))
+args.grad_bucket_mb = 0.004                      # about 1000 floats per bucket: more than 8 buckets in flight during backward
+model = args.Model(GlobalStep(3), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
+assert model.bucketer.reduce and model.bucketer.host_stage and model.bucketer.world == 2 and len(model.bucketer.bounds) > 8
+full = make_batch(B=4, Traw=30, V=11, L=6, U=3, Lb=5, bert_dim=16 if loss_type == 'ctc_kd_ce' else None, dim_raw=4, ragged=True, seed=5)
+half = {k: np.ascontiguousarray(v[2 * rank:2 * rank + 2]) for k, v in full.items()}      # tf.split after padding (lstmModel.py:342-350)
+P0 = model.store.export()
+out4 = model.forward_backward(half).cpu().numpy()
+launched_early = sum(model.bucketer.launched)
+from neurst_amd.st.tools.tftools.gradientTools import average_gradients
+scale = average_gradients(model.bucketer)          # finish(): every bucket reduced (sum over the two ranks)
+torch.cuda.synchronize()
+assert scale == 0.5 and launched_early > 0
+g = {k: v * scale for k, v in model.store.export_grads().items()}
+np.savez(os.path.join(outdir, 'rank%%d.npz' %% rank), loss=out4, **{'g/' + k: v for k, v in g.items()}, **{'p/' + k: v for k, v in P0.items()})
+# two more whole steps (reduce + Adam): both ranks must hold identical parameters afterwards
+for _ in range(2):
+    model.train_step(half)
+torch.cuda.synchronize()
+np.savez(os.path.join(outdir, 'params%%d.npz' %% rank), **model.store.export())
+dist.destroy_process_group()
+print('two-rank worker ok', rank, flush=True)
+"""
+
+
+@pytest.mark.parametrize('loss_type', ['ctc_kd_ce', 'ce_ctc'])
+def test_two_ranks_on_one_gpu_reduce_to_the_full_batch_gradient(tmp_path, loss_type):
+    """a19 with world = 2 on the device (gradientTools.py:7-37, lstmModel.py:342-350): two fresh processes share cuda:0, each
+    runs the real train step (fp32 mode) on its half of a padded batch with the bucketed all-reduce launched during backward;
+    the reduced, averaged gradient must equal the oracle's full-batch gradient (the reference's mean over towers), and after
+    two further steps both ranks hold the same parameters."""
+    import os
+    import subprocess
+    import sys
+    from oracle import ops as oops
+    from oracle.model import OracleTPE
+    script = tmp_path / 'worker.py'
+    script.write_text(TWO_RANK_WORKER % ge.ROOT)
+    port = str(29800 + os.getpid() % 1500)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, str(tmp_path), loss_type], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=140)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and 'two-rank worker ok' in o, 'rank %d:\n%s' % (r, o[-3000:])
+    r0, r1 = (np.load(str(tmp_path / ('rank%d.npz' % r))) for r in range(2))
+    keys = [k[2:] for k in r0.files if k.startswith('g/')]
+    for k in keys:                                   # every rank holds the same reduced gradient and started from the same weights
+        assert np.array_equal(r0['g/' + k], r1['g/' + k]), k
+        assert np.array_equal(r0['p/' + k], r1['p/' + k]), k
+    # oracle: the full batch of 4 in one tower
+    from neurst_amd.synthetic import make_batch
+    args = ge.tiny_args(loss_type=loss_type, compute_dtype='fp32', shrink=(loss_type == 'ce_ctc'))
+    full = make_batch(B=4, Traw=30, V=11, L=6, U=3, Lb=5, bert_dim=16 if loss_type == 'ctc_kd_ce' else None, dim_raw=4, ragged=True, seed=5)
+    cfg = ge.oracle_cfg_from_args(args).zero_dropout()
+    feat, lens = oops.splice_downsample_batch(full['feature'], full['len_fea'], 5, 3)
+    P = {k: r0['p/' + k] for k in keys}
+    ref = OracleTPE(cfg, is_train=True, dropout=False).loss_and_grads(P, dict(full, feature=feat, len_fea=lens))
+    mean_loss = 0.5 * (float(r0['loss'][0]) + float(r1['loss'][0]))
+    if loss_type == 'ce_ctc':                        # without the KD term the loss is a plain mean over utterances
+        assert abs(mean_loss - ref['loss']) <= 1e-5 * abs(ref['loss']), (mean_loss, ref['loss'])
+    for k, v in ref['grads'].items():
+        if loss_type == 'ctc_kd_ce' and v.size == 0:
+            continue
+        err = np.abs(r0['g/' + k] - v).max()
+        assert err <= 5e-5 * max(np.abs(v).max(), 1e-6) + 1e-7, (k, err, np.abs(v).max())
+    pa, pb = (np.load(str(tmp_path / ('params%d.npz' % r))) for r in range(2))
+    for k in pa.files:
+        assert np.array_equal(pa[k], pb[k]), k
+
+
 def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
     """bench.py's contract: stdout is ONE JSON line (library banners go to stderr) carrying the driver's keys and the
     roofline object; under torch.distributed.run with one rank the same holds (RCCL prints a version banner to stdout)"""

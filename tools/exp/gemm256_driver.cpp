@@ -1,0 +1,141 @@
+// Checks the 256 x 256-tile GEMM kernel against the 128 x 128 kernels (bit-exact on small-integer operands: every partial
+// sum is an exact fp32 integer, so the summation order cannot matter) and times both back-to-back on random operands.
+// hipcc --offload-arch=gfx950 -O2 gemm256_driver.cpp -o gemm256_driver -L../../neurst_amd -lneurst_hip -Wl,-rpath,'$ORIGIN/../../neurst_amd'
+//   gemm256_driver check | time | all
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../include/neurst_hip.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
+struct Shape { const char* name; int64_t M, N, K; int ta, tb, cf32, bias, relu, gate, acc; };
+
+int main(int argc, char** argv) {
+  const char* mode = argc > 1 ? argv[1] : "all";
+  const size_t maxe = 16000ull * 10000;
+  void *A, *B, *C0, *C1, *G; float* bias;
+  CK(hipMalloc(&A, maxe * 2)); CK(hipMalloc(&B, maxe * 2)); CK(hipMalloc(&C0, maxe * 4)); CK(hipMalloc(&C1, maxe * 4)); CK(hipMalloc(&G, maxe * 2));
+  CK(hipMalloc(&bias, 65536 * 4));
+  int bad = 0;
+  if (!strcmp(mode, "check") || !strcmp(mode, "all")) {
+    // integers in [-3, 3]: |sum| <= 9 K < 2^24 for K <= 16000 x ...; bias integers; gate signs
+    std::vector<unsigned short> h(1 << 22);
+    unsigned s = 777;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = f2bf((float)((int)((s >> 20) % 7) - 3)); }
+    for (size_t off = 0; off < maxe; off += h.size()) {
+      size_t n = maxe - off < h.size() ? maxe - off : h.size();
+      CK(hipMemcpy((char*)A + off * 2, h.data(), n * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy((char*)G + off * 2, h.data() + 1, (n - 1) * 2, hipMemcpyHostToDevice));
+    }
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = f2bf((float)((int)((s >> 20) % 5) - 2)); }
+    for (size_t off = 0; off < maxe; off += h.size()) {
+      size_t n = maxe - off < h.size() ? maxe - off : h.size();
+      CK(hipMemcpy((char*)B + off * 2, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    std::vector<float> hb(65536);
+    for (auto& v : hb) { s = s * 1664525u + 1013904223u; v = (float)((int)((s >> 20) % 9) - 4); }
+    CK(hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    std::vector<Shape> shapes = {
+        {"NT 512x512x128", 512, 512, 128, 0, 1, 0, 0, 0, 0, 0},
+        {"NT 256x256x64", 256, 256, 64, 0, 1, 1, 0, 0, 0, 0},
+        {"NT ragged 300x520x200 bias relu", 300, 520, 200, 0, 1, 0, 1, 1, 0, 0},
+        {"NT ragged f32 acc 777x264x72", 777, 264, 72, 0, 1, 1, 1, 0, 0, 1},
+        {"NT K odd tiles 1000x768x448", 1000, 768, 448, 0, 1, 0, 1, 0, 0, 0},
+        {"NT K tail 1030x776x1000", 1030, 776, 1000, 0, 1, 0, 0, 0, 0, 0},
+        {"NN 1000x768x448 gate", 1000, 768, 448, 0, 0, 0, 0, 0, 1, 0},
+        {"NN K tail 520x264x1000", 520, 264, 1000, 0, 0, 1, 0, 0, 0, 0},
+        {"TN 768x520x1000 f32 acc", 768, 520, 1000, 1, 0, 1, 0, 0, 0, 1},
+        {"TN 264x776x520", 264, 776, 520, 1, 0, 0, 1, 0, 0, 0},
+        {"TT 520x264x456", 520, 264, 456, 1, 1, 0, 0, 0, 0, 0},
+        {"NT enc qkv", 16000, 2304, 768, 0, 1, 0, 1, 0, 0, 0},
+        {"NT enc ffn1 relu", 16000, 3072, 768, 0, 1, 0, 1, 1, 0, 0},
+        {"NT enc ffn2", 16000, 768, 3072, 0, 1, 0, 1, 0, 0, 0},
+        {"NN enc dgrad ffn2 gate", 16000, 3072, 768, 0, 0, 0, 0, 0, 1, 0},
+        {"NN enc dgrad qkv", 16000, 768, 2304, 0, 0, 0, 0, 0, 0, 0},
+        {"NN ctc head f32", 16000, 10000, 768, 0, 0, 1, 0, 0, 0, 0},
+        {"NT dgrad ctc K=10000", 16000, 768, 10000, 0, 1, 0, 0, 0, 0, 0},
+        {"TN wgrad-like 3072x768x16000 f32 acc", 3072, 768, 16000, 1, 0, 1, 0, 0, 0, 1},
+    };
+    neurst_set_option("gemm256_min_tiles", 1);
+    for (auto& sh : shapes) {
+      const int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.K : sh.N, ldc = sh.N;
+      const size_t cbytes = (size_t)sh.M * sh.N * (sh.cf32 ? 4 : 2);
+      void* Cs[2] = {C0, C1};
+      for (int which = 0; which < 2; ++which) {
+        neurst_set_option("gemm256", which);
+        CK(hipMemset(Cs[which], sh.acc ? 0x00 : 0xff, cbytes));      // accumulate: start from zeros; else poison
+        if (sh.acc) { float one = 0; (void)one; }
+        for (int rep = 0; rep < (which ? 3 : 1); ++rep) {            // the new kernel three times (races show as differences)
+          if (rep) CK(hipMemset(Cs[which], sh.acc ? 0x00 : 0xff, cbytes));
+          int rc = neurst_gemm_bias_act(A, B, Cs[which], sh.bias ? bias : nullptr, sh.gate ? G : nullptr, sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta,
+                                        sh.tb, NEURST_BF16, sh.cf32 ? NEURST_F32 : NEURST_BF16, sh.relu, sh.acc, 1, nullptr);
+          if (rc) { printf("gemm error %s\n", neurst_last_error()); return 1; }
+          CK(hipDeviceSynchronize());
+          if (which) {
+            std::vector<unsigned char> h0(cbytes), h1(cbytes);
+            CK(hipMemcpy(h0.data(), C0, cbytes, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h1.data(), C1, cbytes, hipMemcpyDeviceToHost));
+            size_t ndiff = 0, first = 0;
+            const size_t es = sh.cf32 ? 4 : 2;
+            for (size_t i = 0; i < cbytes; i += es)
+              if (memcmp(&h0[i], &h1[i], es)) { if (!ndiff) first = i / es; ++ndiff; }
+            printf("%-40s rep %d: %s (%zu of %zu differ%s)\n", sh.name, rep, ndiff ? "MISMATCH" : "ok", ndiff, cbytes / es, "");
+            if (ndiff) {
+              ++bad;
+              printf("   first at row %zu col %zu\n", first / sh.N, first % sh.N);
+              size_t rows_bad[8] = {0}; (void)rows_bad;
+            }
+          }
+        }
+      }
+    }
+    printf(bad ? "CHECK FAILED (%d)\n" : "CHECK OK\n", bad);
+  }
+  if (!strcmp(mode, "time") || !strcmp(mode, "all")) {
+    std::vector<unsigned short> h(1 << 24);
+    unsigned s = 12345;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 16) & 0x807f) | 0x3f00 | ((s >> 9) & 0x0080)); }
+    for (size_t off = 0; off + h.size() <= maxe; off += h.size()) {
+      CK(hipMemcpy((char*)A + off * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy((char*)B + off * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
+    CK(hipMemset(bias, 0, 65536 * 4));
+    std::vector<Shape> shapes = {
+        {"enc qkv NT", 16000, 2304, 768, 0, 1, 0, 1, 0, 0, 0},        {"enc ffn1 NT relu", 16000, 3072, 768, 0, 1, 0, 1, 1, 0, 0},
+        {"enc ffn2 NT", 16000, 768, 3072, 0, 1, 0, 1, 0, 0, 0},       {"enc out NT", 16000, 768, 768, 0, 1, 0, 1, 0, 0, 0},
+        {"dec kv NT", 16000, 1536, 768, 0, 1, 0, 1, 0, 0, 0},         {"enc fc NT K=480", 16000, 768, 480, 0, 1, 0, 0, 0, 0, 0},
+        {"enc dgrad qkv NN", 16000, 768, 2304, 0, 0, 0, 0, 0, 0, 0},  {"enc dgrad ffn2 NN gate", 16000, 3072, 768, 0, 0, 0, 0, 0, 1, 0},
+        {"enc dgrad ffn1 NN", 16000, 768, 3072, 0, 0, 0, 0, 0, 0, 0}, {"enc dgrad out NN", 16000, 768, 768, 0, 0, 0, 0, 0, 0, 0},
+        {"ctc head NN f32", 16000, 10000, 768, 0, 0, 1, 0, 0, 0, 0},  {"dgrad ctc NT K=10000", 16000, 768, 10000, 0, 1, 0, 0, 0, 0, 0},
+        {"costt ffn1 NT", 16000, 2048, 512, 0, 1, 0, 1, 1, 0, 0},     {"costt qkv NT", 16000, 1536, 512, 0, 1, 0, 1, 0, 0, 0},
+        {"square 8192 NT", 8192, 8192, 8192, 0, 1, 0, 0, 0, 0, 0},    {"square 4096 NT", 4096, 4096, 4096, 0, 1, 0, 0, 0, 0, 0},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    neurst_set_option("gemm256_min_tiles", 1);
+    for (auto& sh : shapes) {
+      const int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.K : sh.N, ldc = sh.N;
+      float us[2] = {0, 0};
+      for (int round = 0; round < 3; ++round)
+        for (int which = 0; which < 2; ++which) {
+          neurst_set_option("gemm256", which);
+          const int iters = 20;
+          CK(hipEventRecord(e0, 0));
+          for (int i = 0; i < iters; ++i) {
+            int rc = neurst_gemm_bias_act(A, B, C0, sh.bias ? bias : nullptr, sh.gate ? G : nullptr, sh.M, sh.N, sh.K, lda, ldb, ldc, sh.ta, sh.tb,
+                                          NEURST_BF16, sh.cf32 ? NEURST_F32 : NEURST_BF16, sh.relu, sh.acc, 1, nullptr);
+            if (rc) { printf("gemm error %s\n", neurst_last_error()); return 1; }
+          }
+          CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          if (round) us[which] = (round == 1 ? ms * 1e3f / iters : (us[which] < ms * 1e3f / iters ? us[which] : ms * 1e3f / iters));
+        }
+      const double fl = 2.0 * sh.M * sh.N * sh.K;
+      printf("%-26s M=%5ld N=%5ld K=%5ld  128-tile %8.1f us %7.1f TF/s | 256-tile %8.1f us %7.1f TF/s  (x%.2f)\n", sh.name, (long)sh.M, (long)sh.N,
+             (long)sh.K, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, us[0] / us[1]);
+    }
+  }
+  return bad ? 2 : 0;
+}
