@@ -610,12 +610,16 @@ extern "C" int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, fl
 
 // run-time switches (tests and A/B timing run both kernels in one process); initialised from the environment
 static int g_opt_gemm256 = [] { const char* e = getenv("NEURST_GEMM256"); return e ? atoi(e) : 1; }();
+int g_opt_gemm256_bn = 0;
+int g_opt_gemm256_ablate = 0;
 int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TILES"); return e ? atoi(e) : 128; }();
 static bool use_gemm256() { return g_opt_gemm256 != 0; }
 extern "C" int neurst_set_option(const char* name, int value) {
   NEURST_CHECK_ARG(name, "set_option: null name");
   if (!strcmp(name, "gemm256")) g_opt_gemm256 = value;
   else if (!strcmp(name, "gemm256_min_tiles")) g_opt_gemm256_min_tiles = value;
+  else if (!strcmp(name, "gemm256_bn")) g_opt_gemm256_bn = value;
+  else if (!strcmp(name, "gemm256_ablate")) g_opt_gemm256_ablate = value;
   else { neurst_set_error("set_option: unknown option '%s'", name); return NEURST_E_INVALID; }
   return NEURST_OK;
 }
@@ -639,7 +643,7 @@ extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const
   if (ab_dtype == NEURST_BF16) {
     // FAST: direct-to-LDS staging needs 16-byte aligned rows and whole 8-element chunks along every contiguous axis
     const bool fast = g.a_aligned && g.b_aligned && K % 8 == 0 && (!trans_a || M % 8 == 0) && (trans_b || N % 8 == 0);
-    if (fast && use_gemm256() && neurst_gemm256_eligible(g, trans_a, trans_b)) {
+    if (fast && use_gemm256() && neurst_gemm256_eligible(g, trans_a, trans_b, c_dtype == NEURST_F32)) {
       neurst_gemm256_launch(g, trans_a, trans_b, c_dtype, s);
       NEURST_CHECK_LAUNCH("gemm256");
       return NEURST_OK;

@@ -14,7 +14,7 @@
 //    phase 0: C[m0][n0] += A0.B0, phase 1: C[m0][n1] += A0.B1, phase 2: C[m1][n1] += A1.B1, phase 3: C[m1][n0] += A1.B0
 //    (16 MFMAs per wave and phase).  Pieces are numbered s = 4 * (K-tile) + piece and live in LDS slot s mod 8.
 //  * Every phase issues ONE piece, 6 pieces ahead of the one numbered like the phase (2 buffer_load ... lds per thread),
-//    and waits with a COUNTED vmcnt(8) for the pieces the next phase reads: four pieces (64 KiB per CU) stay in flight
+//    and waits with a COUNTED vmcnt for the pieces the next phase reads: four pieces (64 KiB per CU) stay in flight
 //    across the barriers.  Slot reuse: piece s+8 is issued in phase s+2, at least two phases after the last read of
 //    piece s; a piece is read one phase after the wait + barrier that retires it (both groups of waves, see below).
 //  * The waves of wave-row 1 run one barrier behind those of wave-row 0 (waves w and w+4 share a SIMD): while one of the
@@ -61,27 +61,46 @@ typedef Stager<bf16_t, true, 64> ST;                           // k-strided piec
 
 // Byte offset, relative to the operand's (tile, K-tile) origin, of the 16-byte chunk this thread fetches in issue i (0, 1)
 // of the piece holding half `sub` (0, 1) of every wave row's A rows (IS_A) or of every wave column's B columns.
-template <bool KSTRIDED, bool IS_A>
+// WN = columns per wave (64 or 48); the second B piece then holds 32 or 16 columns per wave.  Returns OOB for the
+// positions of an LDS image that no operand element belongs to (k-strided second B piece of a 48-column wave tile).
+template <bool KSTRIDED, bool IS_A, int WN>
 __device__ __forceinline__ int piece_voff(int tid, int i, int sub, int64_t ld) {
+  constexpr int W1 = WN - 32;                                  // columns per wave in the second B piece: 32 or 16
   if constexpr (!KSTRIDED) {
     const int r = i * 64 + (tid >> 3);                         // row of the LDS image
     const int c = (tid & 7) ^ (r & 7);                         // source chunk that belongs at LDS chunk position tid & 7
-    const int row = IS_A ? (r >> 6) * 128 + sub * 64 + (r & 63) : (r >> 5) * 64 + sub * 32 + (r & 31);
+    int row;
+    if constexpr (IS_A) row = (r >> 6) * 128 + sub * 64 + (r & 63);
+    else if (sub == 0) row = (r >> 5) * WN + (r & 31);
+    else row = (r / W1) * WN + 32 + (r % W1);
     return (int)(row * ld * 2) + c * 16;
   } else {
     const int P = i * 512 + tid;
     const int r = P >> 4;                                      // k row of the LDS image
     const int c = (P & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
-    const int col = IS_A ? (c >> 3) * 128 + sub * 64 + (c & 7) * 8 : (c >> 2) * 64 + sub * 32 + (c & 3) * 8;
+    int col;
+    if constexpr (IS_A) col = (c >> 3) * 128 + sub * 64 + (c & 7) * 8;
+    else if (sub == 0) col = (c >> 2) * WN + (c & 3) * 8;
+    else {
+      constexpr int CW = W1 / 8;                               // chunks per wave: 4 or 2
+      if (c >= 4 * CW) return OOB;
+      col = (c / CW) * WN + 32 + (c % CW) * 8;
+    }
     return (int)(r * ld * 2) + col * 2;
   }
 }
 
 struct Args {
   GemmArgs g;
-  int nk;                 // K-tiles per output tile
-  int rounds_total;       // unused (kept for debugging)
+  int nk;                 // K-tiles per output tile (even)
+  unsigned long long* stamps;   // diagnostic instantiation only: [workgroup][24] clock readings
+  int ablate;                   // diagnostic instantiation only: timing-only ablations of the K loop (wrong results)
 };
+__device__ __forceinline__ unsigned long long clk() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
 
 template <bool KSTRIDED>
 __device__ __forceinline__ bf16x8 frag(const bf16_t* __restrict__ piece, int first, int ks, int lane) {
@@ -89,9 +108,90 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* __restrict__ piece, int fir
   else return ST::frag(piece, first, ks, lane);
 }
 
-template <typename TC, bool TA, bool TBK>
+// Accumulators of one wave (8 x NI MFMA tiles = 128 rows x 16 NI columns) -> C, with bias / ReLU / ReLU-gradient gate /
+// accumulate.  Per 16 rows and 32 columns: MFMA layout -> this wave's LDS staging tile -> 8 consecutive columns per lane,
+// so that every lane stores 16 bytes (bf16) or 2 x 16 bytes (fp32) of one row.
+template <typename TC, int NI>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI], const float (&bcol)[NI], float* __restrict__ Cs,
+                                         int64_t wrow0, int64_t wcol0, int lane) {
+  TC* C = reinterpret_cast<TC*>(g.C);
+  const bf16_t* rs = reinterpret_cast<const bf16_t*>(g.relu_src);
+  const int lg = lane >> 4, l15 = lane & 15;
+  const int rr = lane >> 2, cc = (lane & 3) * 8;
+  constexpr int NH = (NI + 1) / 2;                             // 32-column halves (the last one may hold 16 columns)
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int jh = 0; jh < NH; ++jh) {
+      constexpr int dummy = 0; (void)dummy;
+      const int nj = NI - 2 * jh < 2 ? NI - 2 * jh : 2;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (jj < nj) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][jh * 2 + jj][r] + bcol[jh * 2 + jj];
+            if (g.relu) v = fmaxf(v, 0.f);
+            Cs[(lg * 4 + r) * PEPI_LD + jj * 16 + l15] = v;
+          }
+        }
+      // the same wave reads back what it wrote: LDS operations of one wave complete in order
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + rr * PEPI_LD + cc);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + rr * PEPI_LD + cc + 4);
+      const int64_t row = wrow0 + i * 16 + rr, col = wcol0 + jh * 32 + cc;
+      if (cc >= nj * 16 || row >= g.M || col >= g.N) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      const int64_t off = row * g.ldc + col;
+      if (g.c_vec && col + 8 <= g.N) {
+        if (rs) {
+          const bf16x8 m = *reinterpret_cast<const bf16x8*>(rs + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)m[e] > 0.f ? v[e] : 0.f;
+        }
+        if constexpr (sizeof(TC) == 2) {
+          if (g.accumulate) {
+            const bf16x8 old = *reinterpret_cast<const bf16x8*>(C + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(C + off) = o;
+        } else {
+          f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          if (g.accumulate) {
+            o0 += *reinterpret_cast<const f32x4*>(C + off);
+            o1 += *reinterpret_cast<const f32x4*>(C + off + 4);
+          }
+          *reinterpret_cast<f32x4*>(C + off) = o0;
+          *reinterpret_cast<f32x4*>(C + off + 4) = o1;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (col + e >= g.N) continue;
+          float x = v[e];
+          if (rs) x = (float)rs[off + e] > 0.f ? x : 0.f;
+          if (g.accumulate) x += to_f32<TC>(C[off + e]);
+          C[off + e] = from_f32<TC>(x);
+        }
+      }
+    }
+}
+
+// NI1 = MFMA tiles (16 columns each) per wave in the SECOND B piece: 2 -> 256-column output tiles, 1 -> 192-column tiles
+// (wave tile 128 x 48; M = 16000 rows give 63 tile rows, so tile counts that are multiples of 4 per tile row fill 256 CUs
+// in whole rounds: N = 768 -> 252 tiles, 2304 -> 756, 1536 -> 504).
+template <typename TC, bool TA, bool TBK, int NI1 = 2, bool STAMPS = false, int ABL = 0>
 __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
   constexpr bool AKS = TA, BKS = !TBK;                         // operand is k-strided in memory
+  constexpr int NI = 2 + NI1, WN = 16 * NI, BNT = 4 * WN;      // MFMA tiles / columns per wave, columns per output tile
+  // loads per thread of the four piece kinds (a K-contiguous second B piece of 64 rows is ONE issue)
+  constexpr int NL2 = (NI1 == 1 && !BKS) ? 1 : 2;
+  constexpr int NLOAD[4] = {2, 2, NL2, 2};
   const GemmArgs& g = args.g;
   __shared__ __attribute__((aligned(16))) char smem[RING_BYTES + EPI_BYTES];   // ONE LDS object
   bf16_t* const ring = reinterpret_cast<bf16_t*>(smem);
@@ -124,9 +224,19 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
     const int group = t / per_group, first_m = group * GM;
     const int gsz = g.tiles_m - first_m < GM ? g.tiles_m - first_m : GM;
     m0 = (int64_t)(first_m + (t % per_group) % gsz) * BM;
-    n0 = (int64_t)((t % per_group) / gsz) * BN;
+    n0 = (int64_t)((t % per_group) / gsz) * BNT;
   };
   if (tile_at(0) < 0) return;                                  // whole workgroup: nothing to do
+  unsigned long long* const stamp = STAMPS ? args.stamps + (size_t)blockIdx.x * 24 : nullptr;
+  auto put = [&](int i) __attribute__((always_inline)) {
+    if constexpr (STAMPS) {
+      if (!args.stamps) return;
+      const unsigned long long t = clk();
+      if (tid == 0 && i < 24) stamp[i] = t;
+    }
+  };
+  if constexpr (STAMPS) { if (tid == 0 && args.stamps) stamp[23] = __builtin_amdgcn_s_memrealtime(); }
+  put(0);
 
   // ---- per-thread source offsets of the four piece kinds
   int voA[2][2], voB[2][2];
@@ -134,8 +244,8 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
   for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      voA[sub][i] = piece_voff<AKS, true>(tid, i, sub, g.lda);
-      voB[sub][i] = piece_voff<BKS, false>(tid, i, sub, g.ldb);
+      voA[sub][i] = piece_voff<AKS, true, WN>(tid, i, sub, g.lda);
+      voB[sub][i] = piece_voff<BKS, false, WN>(tid, i, sub, g.ldb);
     }
   const int kc8 = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;          // first k of this thread's chunk in a K-contiguous piece
 
@@ -180,116 +290,133 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
     set_rsrc();
   };
   set_rsrc();
-  // piece kind 0: B sub 0, 1: A sub 0, 2: B sub 1, 3: A sub 1 of the cursor's K-tile, into LDS slot `slot`
-  auto issue = [&](int kind, int slot) __attribute__((always_inline)) {
+  // issue i (0, 1) of piece kind 0: B sub 0, 1: A sub 0, 2: B sub 1, 3: A sub 1 of the cursor's K-tile, into LDS slot `slot`
+  constexpr int abl = ABL;                                     // timing-only ablations (diagnostic instantiations)
+  // The two DMA instructions of a phase's piece are issued in its LOAD segment, one before and one after the LDS reads:
+  // each costs the issuing wave 60-180 cycles (the per-CU load path takes ~33 cycles per 1-KiB instruction and is as busy
+  // as the matrix pipe: 64 KiB against 8.4 MFLOP per K-tile), which the partner wave's MFMAs cover.  Issued between the
+  // MFMAs instead (ABL bit 64 of the diagnostic instantiations) the K loop measured 9 % slower.
+  constexpr bool DMA_IN_LOAD = (ABL & 64) == 0;
+  auto issue1 = [&](int kind, int slot, int i) __attribute__((always_inline)) {
+    if (i >= NLOAD[kind]) return;
+    if constexpr ((abl & 1) != 0) return;
     const bool isA = kind & 1;
     const int sub = kind >> 1;
     const unsigned dst = lds0 + (unsigned)(slot * PIECE + wave * 512) * 2;   // this wave's 1 KiB of each 8 KiB issue
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int vo = isA ? voA[sub][i] : voB[sub][i];
-      // partial last K-tile of a K-contiguous operand: chunks at or beyond K must read as zero (a k-strided operand gets
-      // that from the range check: rows beyond K lie beyond its end)
-      if (l_krem < BK && !(isA ? AKS : BKS)) vo = kc8 < l_krem ? vo : OOB;
-      dma16(isA ? rsA : rsB, dst + i * 8192, vo);
-    }
+    int vo = isA ? voA[sub][i] : voB[sub][i];
+    // partial last K-tile of a K-contiguous operand: chunks at or beyond K must read as zero (a k-strided operand gets
+    // that from the range check: rows beyond K lie beyond its end)
+    if (l_krem < BK && !(isA ? AKS : BKS)) vo = kc8 < l_krem ? vo : OOB;
+    dma16(isA ? rsA : rsB, dst + i * 8192, vo);
   };
+  auto issue = [&](int kind, int slot) __attribute__((always_inline)) { issue1(kind, slot, 0); issue1(kind, slot, 1); };
 
   // ---- prologue: pieces 0..5
   issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
   advance_k();
   issue(0, 4); issue(1, 5);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // pieces 0 and 1 of this wave have landed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NL2) : "memory");   // pieces 0 and 1 of this wave have landed
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();                   // wave row 1 runs one barrier behind wave row 0
   __builtin_amdgcn_sched_barrier(0);
 
-  f32x4 acc[8][4];
-  bf16x8 af[4][2], b0[2][2], b1[2][2];
+  put(1);
+  f32x4 acc[8][NI];
+  bf16x8 af[4][2], b0[2][2], b1[NI1][2];
 
-  // one K-tile = 4 phases; PAR = parity of the K-tile's global index (LDS slots 4 PAR .. 4 PAR + 3)
+  // 4 x NB x 2 MFMAs of one phase with the two DMA issues of piece `kind` spread among them: the issue of an LDS-DMA
+  // instruction takes 60-180 cycles of the wave, which are hidden here behind the matrix pipe instead of lengthening the
+  // load segment that the partner wave on the SIMD waits for at the next barrier
+  auto compute = [&](auto mo_c, auto no_c, auto nb_c, bf16x8 (&bf)[decltype(nb_c)::value][2], int kind, int slot) __attribute__((always_inline)) {
+    constexpr int MO = decltype(mo_c)::value, NO = decltype(no_c)::value, NB = decltype(nb_c)::value;
+    if constexpr ((abl & 16) == 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+          if constexpr ((abl & 4) == 0)
+            acc[MO + mi][NO + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], bf[ni][ks], acc[MO + mi][NO + ni], 0, 0, 0);
+          else asm volatile("" ::"v"(af[mi][ks]), "v"(bf[ni][ks]));   // keeps the LDS reads alive
+        if constexpr (!DMA_IN_LOAD) {
+          if (mi == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue1(kind, slot, ks);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I2 = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  using IN1 = std::integral_constant<int, NI1>;
+#define T2_RD(x) do { if constexpr ((abl & 2) == 0) { x; } } while (0)
+#define T2_BAR2() do { if constexpr ((abl & 8) == 0) __builtin_amdgcn_s_barrier(); } while (0)
+#define T2_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+  // one K-tile = 4 phases; PAR = parity of the K-tile's global index (LDS slots 4 PAR .. 4 PAR + 3).  Phase p issues
+  // piece p + 6 during its MFMAs; before its first barrier it waits for the pieces phase p + 1 reads (up to p + 2), with
+  // pieces p + 3 .. p + 5 still in flight.
   auto ktile = [&](auto par_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
     const bf16_t* const s0 = ring + (4 * PAR + 0) * PIECE;
     const bf16_t* const s1 = ring + (4 * PAR + 1) * PIECE;
     const bf16_t* const s2 = ring + (4 * PAR + 2) * PIECE;
     const bf16_t* const s3 = ring + (4 * PAR + 3) * PIECE;
-    // ---------------- phase 0
+    // ---------------- phase 0: newer than piece p + 2 are kinds 3, 0, 1
+    if constexpr (DMA_IN_LOAD) { issue1(2, (4 * PAR + 6) & 7, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = frag<BKS>(s0, wc * 32 + ni * 16, ks * 32, lane);
+      for (int ks = 0; ks < 2; ++ks) T2_RD(b0[ni][ks] = frag<BKS>(s0, wc * 32 + ni * 16, ks * 32, lane));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[mi][ks] = frag<AKS>(s1, wr * 64 + mi * 16, ks * 32, lane);
-    issue(2, (4 * PAR + 6) & 7);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      for (int ks = 0; ks < 2; ++ks) T2_RD(af[mi][ks] = frag<AKS>(s1, wr * 64 + mi * 16, ks * 32, lane));
+    if constexpr (DMA_IN_LOAD) { __builtin_amdgcn_sched_barrier(0); issue1(2, (4 * PAR + 6) & 7, 1); T2_WAIT(6 + NL2); } else
+    T2_WAIT(6);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    compute(I0{}, I0{}, I2{}, b0, 2, (4 * PAR + 6) & 7);
+    T2_BAR2();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- phase 1: newer are kinds 0, 1, 2
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ni = 0; ni < NI1; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b0[ni][ks], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+      for (int ks = 0; ks < 2; ++ks) T2_RD(b1[ni][ks] = frag<BKS>(s2, wc * (16 * NI1) + ni * 16, ks * 32, lane));
+    if constexpr (DMA_IN_LOAD) { __builtin_amdgcn_sched_barrier(0); issue(3, (4 * PAR + 7) & 7); T2_WAIT(6 + NL2); } else
+    T2_WAIT(4 + NL2);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- phase 1
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = frag<BKS>(s2, wc * 32 + ni * 16, ks * 32, lane);
-    issue(3, (4 * PAR + 7) & 7);
+    compute(I0{}, I2{}, IN1{}, b1, 3, (4 * PAR + 7) & 7);
     advance_k();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    T2_BAR2();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b1[ni][ks], acc[mi][2 + ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- phase 2
+    // ---------------- phase 2: phase 3 reads nothing, no wait
+    if constexpr (DMA_IN_LOAD) { issue1(0, 4 * PAR + 0, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[mi][ks] = frag<AKS>(s3, wr * 64 + mi * 16, ks * 32, lane);
-    issue(0, 4 * PAR + 0);
+      for (int ks = 0; ks < 2; ++ks) T2_RD(af[mi][ks] = frag<AKS>(s3, wr * 64 + mi * 16, ks * 32, lane));
+    if constexpr (DMA_IN_LOAD) { __builtin_amdgcn_sched_barrier(0); issue1(0, 4 * PAR + 0, 1); }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[4 + mi][2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b1[ni][ks], acc[4 + mi][2 + ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    compute(I4{}, I2{}, IN1{}, b1, 0, 4 * PAR + 0);
+    T2_BAR2();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- phase 3: newer are kinds 2, 3, 0
+    if constexpr (DMA_IN_LOAD) { issue(1, 4 * PAR + 1); T2_WAIT(6 + NL2); } else
+    T2_WAIT(4 + NL2);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- phase 3
-    issue(1, 4 * PAR + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[4 + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], b0[ni][ks], acc[4 + mi][ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+    compute(I4{}, I0{}, I2{}, b0, 1, 4 * PAR + 1);
+    T2_BAR2();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -301,29 +428,30 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    put(2 + round * 4);
     for (int kt = 0; kt < nk; kt += 2) {                       // nk is even (an odd count is padded with an all-zero K-tile)
       ktile(std::integral_constant<int, 0>{});
       ktile(std::integral_constant<int, 1>{});
     }
+    put(3 + round * 4);
     // ---- epilogue of this tile; the next tile's first pieces are already in flight
-    float bcol[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias) {
+    float bcol[NI];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t col = n0 + wc * 64 + j * 16 + (lane & 15);
-        bcol[j] = col < g.N ? g.bias[col] : 0.f;
-      }
+    for (int j = 0; j < NI; ++j) {
+      const int64_t col = n0 + wc * WN + j * 16 + (lane & 15);
+      bcol[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
     }
-    // in two halves of 64 rows: the ReLU-gate prefetch of the epilogue then holds 32 registers beside the 128 accumulators
-    persist_epilogue<bf16_t, TC, 4>(g, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), bcol, Cs, m0 + wr * 128, n0 + wc * 64, lane);
-    persist_epilogue<bf16_t, TC, 4>(g, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]), bcol, Cs, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+    epilogue<TC, NI>(g, acc, bcol, Cs, m0 + wr * 128, n0 + wc * WN, lane);
+    put(4 + round * 4);
     // the stores above are younger than the pieces in flight: drain everything, so that the counted waits of the next
     // tile's first phases again count only pieces
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    put(5 + round * 4);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // pieces issued past the last tile (out of range: no data)
   if (wr == 0) __builtin_amdgcn_s_barrier();                   // balance the stagger
+  if constexpr (STAMPS) { put(21); if (tid == 0 && args.stamps) stamp[22] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 }  // namespace t2
@@ -331,34 +459,79 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
 // The 256 x 256 kernel takes a problem when it is large enough to fill the chip with 256-wide tiles and its operands can be
 // addressed by 32-bit byte offsets from a tile origin.  trans_a: A stored [K][M]; trans_b: B stored [N][K].
 extern int g_opt_gemm256_min_tiles;                          // gemm.hip: neurst_set_option("gemm256_min_tiles", n)
+extern int g_opt_gemm256_ablate;
+extern int g_opt_gemm256_bn;                                 // 0 = choose per problem, 192 / 256 = forced
 static int t2_min_tiles() { return g_opt_gemm256_min_tiles; }
-bool neurst_gemm256_eligible(const GemmArgs& g, int trans_a, int trans_b) {
+// Column width of the output tile: 256 or 192.  Cost model (measured, tools/exp/gemm256_driver): a round of 256-wide tiles
+// costs its K loop plus a fixed ~15 % (epilogue, seam); a 192-wide tile 3/4 of that; the chip works in rounds of 256 tiles.
+static int t2_pick_bn(const GemmArgs& g) {
+  if (g_opt_gemm256_bn == 192 || g_opt_gemm256_bn == 256) return g_opt_gemm256_bn;
+  const int64_t tm = cdiv64(g.M, t2::BM);
+  double best = 0;
+  int pick = 256;
+  for (int bn : {256, 192}) {
+    const int64_t tiles = tm * cdiv64(g.N, bn), rounds = cdiv64(tiles, 256);
+    const double cost = (double)rounds * (bn / 256.0 + 0.15);
+    if (best == 0 || cost < best - 1e-9) { best = cost; pick = bn; }
+  }
+  return pick;
+}
+bool neurst_gemm256_eligible(const GemmArgs& g, int trans_a, int trans_b, bool c_f32) {
   if (g.split_k != 1 || g.opsum) return false;
   if (!g.a_aligned || !g.b_aligned || g.K % 8 || (trans_a && g.M % 8) || (!trans_b && g.N % 8)) return false;
-  const int64_t tm = cdiv64(g.M, t2::BM), tn = cdiv64(g.N, t2::BN);
+  const int64_t tm = cdiv64(g.M, t2::BM), tn = cdiv64(g.N, t2_pick_bn(g));
   if (tm * tn < t2_min_tiles()) return false;
+  // Where it wins over the 128 x 128 kernels (tools/exp/gemm256_driver, M = 16000): an output tile costs ~10k cycles of
+  // epilogue (all workgroups store at once: HBM-write bound) plus ~3300 cycles per K-tile, so long K loops pay - K = 3072
+  // x1.13 (NT), K = 10000 x1.46 - and so does the fp32 vocabulary projection (x1.10); at K = 768 the 128-tile kernels,
+  // whose co-resident workgroups hide each other's stores, stay ahead (x0.75-0.95).  min_tiles <= 1 (tests, drivers) lifts the rule.
+  if (t2_min_tiles() > 1) {
+    const bool long_k = (g.K >= 2560 && trans_b && !trans_a) || g.K >= 8192;
+    const bool wide_f32 = c_f32 && g.N >= 4096;
+    if (!long_k && !wide_f32) return false;
+  }
   // 32-bit offsets inside one (tile, K-tile) window
   const int64_t wa = trans_a ? 64 * g.lda + 256 : 256 * g.lda + 64;
   const int64_t wb = trans_b ? 256 * g.ldb + 64 : 64 * g.ldb + 256;
   if (wa * 2 >= 0x7fff0000ll || wb * 2 >= 0x7fff0000ll) return false;
   return true;
 }
-template <typename TC>
+static unsigned long long* g_stamps = nullptr;
+// diagnostics (tools/exp/gemm256_driver): with a buffer of 256 x 24 uint64 set, NT launches with bf16 output run an
+// instantiation that records clock readings per workgroup (entry, first compute, per tile: loop start / loop end /
+// stores issued / stores drained, exit)
+extern "C" void neurst_debug_gemm256_stamps(unsigned long long* buf) { g_stamps = buf; }
+template <typename TC, int NI1>
 static void launch256(const GemmArgs& g0, int trans_a, int trans_b, hipStream_t s) {
   t2::Args a;
   a.g = g0;
   a.g.tiles_m = (int)cdiv64(g0.M, t2::BM);
-  a.g.tiles_n = (int)cdiv64(g0.N, t2::BN);
+  a.g.tiles_n = (int)cdiv64(g0.N, 64 * (2 + NI1));
   a.nk = (int)((cdiv64(g0.K, t2::BK) + 1) / 2 * 2);       // even: the K loop runs two K-tiles per iteration
-  a.rounds_total = 0;
+  a.stamps = g_stamps;
+  a.ablate = g_opt_gemm256_ablate;
   const int ntiles = a.g.tiles_m * a.g.tiles_n;
   int grid = ntiles >= 256 ? 256 : (ntiles + 7) / 8 * 8;
-  if (!trans_a && trans_b) t2::gemm256_kernel<TC, false, true><<<grid, t2::NT, 0, s>>>(a);
-  else if (!trans_a && !trans_b) t2::gemm256_kernel<TC, false, false><<<grid, t2::NT, 0, s>>>(a);
-  else if (trans_a && !trans_b) t2::gemm256_kernel<TC, true, false><<<grid, t2::NT, 0, s>>>(a);
-  else t2::gemm256_kernel<TC, true, true><<<grid, t2::NT, 0, s>>>(a);
+  if constexpr (sizeof(TC) == 2) {
+    if (g_stamps && !trans_a && trans_b) { t2::gemm256_kernel<TC, false, true, NI1, true><<<grid, t2::NT, 0, s>>>(a); return; }
+    if constexpr (NI1 == 2) {
+      if (g_opt_gemm256_ablate && !trans_a && trans_b) {
+        switch (g_opt_gemm256_ablate) {
+#define T2_ABL(m) case m: t2::gemm256_kernel<TC, false, true, NI1, false, m><<<grid, t2::NT, 0, s>>>(a); return;
+          T2_ABL(1) T2_ABL(4) T2_ABL(8) T2_ABL(16) T2_ABL(64)
+#undef T2_ABL
+          default: break;
+        }
+      }
+    }
+  }
+  if (!trans_a && trans_b) t2::gemm256_kernel<TC, false, true, NI1><<<grid, t2::NT, 0, s>>>(a);
+  else if (!trans_a && !trans_b) t2::gemm256_kernel<TC, false, false, NI1><<<grid, t2::NT, 0, s>>>(a);
+  else if (trans_a && !trans_b) t2::gemm256_kernel<TC, true, false, NI1><<<grid, t2::NT, 0, s>>>(a);
+  else t2::gemm256_kernel<TC, true, true, NI1><<<grid, t2::NT, 0, s>>>(a);
 }
 void neurst_gemm256_launch(const GemmArgs& g, int trans_a, int trans_b, int c_dtype, hipStream_t s) {
-  if (c_dtype == NEURST_BF16) launch256<bf16_t>(g, trans_a, trans_b, s);
-  else launch256<float>(g, trans_a, trans_b, s);
+  const bool wide = t2_pick_bn(g) == 256;
+  if (c_dtype == NEURST_BF16) { if (wide) launch256<bf16_t, 2>(g, trans_a, trans_b, s); else launch256<bf16_t, 1>(g, trans_a, trans_b, s); }
+  else { if (wide) launch256<float, 2>(g, trans_a, trans_b, s); else launch256<float, 1>(g, trans_a, trans_b, s); }
 }

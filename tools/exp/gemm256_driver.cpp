@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "../../include/neurst_hip.h"
+extern "C" void neurst_debug_gemm256_stamps(unsigned long long* buf);
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
@@ -60,7 +61,9 @@ int main(int argc, char** argv) {
         {"TN wgrad-like 3072x768x16000 f32 acc", 3072, 768, 16000, 1, 0, 1, 0, 0, 0, 1},
     };
     neurst_set_option("gemm256_min_tiles", 1);
+    for (int bn : {256, 192})
     for (auto& sh : shapes) {
+      neurst_set_option("gemm256_bn", bn);
       const int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.K : sh.N, ldc = sh.N;
       const size_t cbytes = (size_t)sh.M * sh.N * (sh.cf32 ? 4 : 2);
       void* Cs[2] = {C0, C1};
@@ -82,7 +85,7 @@ int main(int argc, char** argv) {
             const size_t es = sh.cf32 ? 4 : 2;
             for (size_t i = 0; i < cbytes; i += es)
               if (memcmp(&h0[i], &h1[i], es)) { if (!ndiff) first = i / es; ++ndiff; }
-            printf("%-40s rep %d: %s (%zu of %zu differ%s)\n", sh.name, rep, ndiff ? "MISMATCH" : "ok", ndiff, cbytes / es, "");
+            printf("%-40s bn %d rep %d: %s (%zu of %zu differ%s)\n", sh.name, bn, rep, ndiff ? "MISMATCH" : "ok", ndiff, cbytes / es, "");
             if (ndiff) {
               ++bad;
               printf("   first at row %zu col %zu\n", first / sh.N, first % sh.N);
@@ -117,10 +120,11 @@ int main(int argc, char** argv) {
     neurst_set_option("gemm256_min_tiles", 1);
     for (auto& sh : shapes) {
       const int64_t lda = sh.ta ? sh.M : sh.K, ldb = sh.tb ? sh.K : sh.N, ldc = sh.N;
-      float us[2] = {0, 0};
+      float us[3] = {0, 0, 0};
       for (int round = 0; round < 3; ++round)
-        for (int which = 0; which < 2; ++which) {
-          neurst_set_option("gemm256", which);
+        for (int which = 0; which < 3; ++which) {
+          neurst_set_option("gemm256", which ? 1 : 0);
+          neurst_set_option("gemm256_bn", which == 2 ? 192 : 256);
           const int iters = 20;
           CK(hipEventRecord(e0, 0));
           for (int i = 0; i < iters; ++i) {
@@ -133,8 +137,89 @@ int main(int argc, char** argv) {
           if (round) us[which] = (round == 1 ? ms * 1e3f / iters : (us[which] < ms * 1e3f / iters ? us[which] : ms * 1e3f / iters));
         }
       const double fl = 2.0 * sh.M * sh.N * sh.K;
-      printf("%-26s M=%5ld N=%5ld K=%5ld  128-tile %8.1f us %7.1f TF/s | 256-tile %8.1f us %7.1f TF/s  (x%.2f)\n", sh.name, (long)sh.M, (long)sh.N,
-             (long)sh.K, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, us[0] / us[1]);
+      printf("%-24s %5ldx%5ldx%5ld  128-tile %7.1f us %6.1f TF | 256x256 %7.1f us %6.1f TF (x%.2f) | 256x192 %7.1f us %6.1f TF (x%.2f)\n", sh.name,
+             (long)sh.M, (long)sh.N, (long)sh.K, us[0], fl / us[0] / 1e6, us[1], fl / us[1] / 1e6, us[0] / us[1], us[2], fl / us[2] / 1e6, us[0] / us[2]);
+    }
+    neurst_set_option("gemm256_bn", 0);
+  }
+  if (!strcmp(mode, "ablate")) {
+    // timing-only builds of the K loop (results are wrong): which part of a phase sets its length?
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    {
+      std::vector<unsigned short> h(1 << 24);
+      unsigned s = 12345;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 16) & 0x807f) | 0x3f00 | ((s >> 9) & 0x0080)); }
+      for (size_t off = 0; off + h.size() <= maxe; off += h.size()) {
+        CK(hipMemcpy((char*)A + off * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy((char*)B + off * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      }
+    }
+    neurst_set_option("gemm256_min_tiles", 1); neurst_set_option("gemm256", 1); neurst_set_option("gemm256_bn", 256);
+    const int masks[] = {0, 64, 1, 4, 8, 16};
+    for (int m : masks) {
+      neurst_set_option("gemm256_ablate", m);
+      float best = 1e9;
+      for (int round = 0; round < 3; ++round) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 10; ++i) neurst_gemm_bias_act(A, B, C0, nullptr, nullptr, 8192, 8192, 8192, 8192, 8192, 8192, 0, 1, NEURST_BF16, NEURST_BF16, 0, 0, 1, nullptr);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / 10 < best) best = ms / 10;
+      }
+      printf("ablate %2d (1 no DMA, 4 no MFMA, 8 no 2nd barrier, 16 no setprio, 64 DMA between the MFMAs): 8192^3 %8.1f us = %6.0f cycles/K-tile at 2.0 GHz\n", m, best * 1e3,
+             best * 1e-3 / (4 * 128) * 2.0e9);
+    }
+    neurst_set_option("gemm256_ablate", 0);
+  }
+  if (!strcmp(mode, "stamps") || !strcmp(mode, "all")) {
+    // where one workgroup's time goes (diagnostic instantiation): cycles between the stamps, averaged over workgroups
+    unsigned long long* st; CK(hipMalloc(&st, 256 * 24 * 8));
+    std::vector<Shape> shapes = {{"enc qkv NT", 16000, 2304, 768, 0, 1, 0, 1, 0, 0, 0}, {"enc ffn2 NT", 16000, 768, 3072, 0, 1, 0, 1, 0, 0, 0},
+                                 {"enc ffn1 NT", 16000, 3072, 768, 0, 1, 0, 1, 1, 0, 0}};
+    neurst_set_option("gemm256_min_tiles", 1); neurst_set_option("gemm256", 1);
+    for (int bn : {256, 192})
+    for (auto& sh : shapes) {
+      neurst_set_option("gemm256_bn", bn);
+      printf("bn %d ", bn);
+      std::vector<unsigned long long> h(256 * 24);
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(st, 0, 256 * 24 * 8));
+        neurst_debug_gemm256_stamps(rep == 2 ? st : nullptr);
+        for (int i = 0; i < (rep == 2 ? 1 : 5); ++i)
+          neurst_gemm_bias_act(A, B, C0, bias, nullptr, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, 0, 1, NEURST_BF16, NEURST_BF16, sh.relu, 0, 1, nullptr);
+        CK(hipDeviceSynchronize());
+      }
+      neurst_debug_gemm256_stamps(nullptr);
+      CK(hipMemcpy(h.data(), st, 256 * 24 * 8, hipMemcpyDeviceToHost));
+      printf("%s: per workgroup (cycles; mean over workgroups with that many tiles)\n", sh.name);
+      unsigned long long tmin = ~0ull, tmax = 0;
+      for (int w = 0; w < 256; ++w) if (h[w * 24]) { if (h[w * 24] < tmin) tmin = h[w * 24]; if (h[w * 24 + 21] > tmax) tmax = h[w * 24 + 21]; }
+      double clk = 0; int nclk = 0;
+      for (int w = 0; w < 256; ++w) if (h[w * 24 + 22] > h[w * 24 + 23]) { clk += (double)(h[w * 24 + 21] - h[w * 24]) / (double)(h[w * 24 + 22] - h[w * 24 + 23]) * 100.0; ++nclk; }
+      printf("  kernel span %llu cycles, clock ~%.0f MHz\n", tmax - tmin, nclk ? clk / nclk : 0.0);
+      for (int ntile = 1; ntile <= 4; ++ntile) {
+        double acc[24] = {0}; int cnt = 0;
+        for (int w = 0; w < 256; ++w) {
+          const unsigned long long* r = &h[w * 24];
+          if (!r[0]) continue;
+          int nt = 0; while (nt < 4 && r[2 + nt * 4]) ++nt;
+          if (nt != ntile) continue;
+          ++cnt;
+          acc[0] += (double)(r[1] - r[0]);
+          for (int t = 0; t < nt; ++t) {
+            acc[1 + t * 4] += (double)(r[3 + t * 4] - r[2 + t * 4]);   // K loop
+            acc[2 + t * 4] += (double)(r[4 + t * 4] - r[3 + t * 4]);   // epilogue issue
+            acc[3 + t * 4] += (double)(r[5 + t * 4] - r[4 + t * 4]);   // drain
+            acc[4 + t * 4] += (double)((t + 1 < nt ? r[2 + (t + 1) * 4] : r[21]) - r[5 + t * 4]);   // to next loop / exit
+          }
+          acc[20] += (double)(r[0] - tmin);
+          acc[21] += (double)(r[21] - r[0]);
+        }
+        if (!cnt) continue;
+        printf("  %d workgroups with %d tiles: start offset %.0f, prologue %.0f, total %.0f\n", cnt, ntile, acc[20] / cnt, acc[0] / cnt, acc[21] / cnt);
+        for (int t = 0; t < ntile; ++t)
+          printf("    tile %d: K loop %.0f  epilogue %.0f  drain %.0f  gap %.0f\n", t, acc[1 + t * 4] / cnt, acc[2 + t * 4] / cnt, acc[3 + t * 4] / cnt, acc[4 + t * 4] / cnt);
+      }
     }
   }
   return bad ? 2 : 0;
