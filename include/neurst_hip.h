@@ -78,6 +78,13 @@ int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bia
  * sum_operand 2: opsum[N] += sum_k B[k][n] (B is dY: '[in,out]' kernels).  opsum fp32, accumulated. */
 int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, float* opsum, int sum_operand, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int ab_dtype, int split_k, void* stream);
+/* The same for up to 8 layers in ONE launch (host arrays of n pointers / sizes): problem i is C_i[M_i,N_i] += A_i^T . B_i
+ * with A_i [K_i,M_i] = dY, B_i [K_i,N_i] = X and opsum_i (may be NULL) += column sums of A_i.  bf16 operands run as whole-K
+ * 256 x 192 tiles, one workgroup each (no split-K, no atomics on C): a single encoder-size gradient has 12-48 tiles, so
+ * the caller packs gradients until they fill the 256 CUs (st/models/graph.py).  Other cases: one launch per problem. */
+int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const void* const* B, float* const* C, float* const* opsum,
+                                   const int64_t* M, const int64_t* N, const int64_t* K, const int64_t* lda,
+                                   const int64_t* ldb, const int64_t* ldc, int ab_dtype, void* stream);
 /* column sums (bias gradients): out[n] (+)= sum_m x[m,n]; out fp32. */
 int neurst_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
                   void* stream);

@@ -554,6 +554,21 @@ static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t 
   return launch_gemm_ns<T, TC, FAST, 2>(g, trans_a, trans_b, s);
 }
 
+// run-time switches (tests and A/B timing run both kernels in one process); initialised from the environment
+static int g_opt_gemm256 = [] { const char* e = getenv("NEURST_GEMM256"); return e ? atoi(e) : 1; }();
+int g_opt_gemm256_bn = 0;
+int g_opt_gemm256_ablate = 0;
+int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TILES"); return e ? atoi(e) : 128; }();
+static bool use_gemm256() { return g_opt_gemm256 != 0; }
+extern "C" int neurst_set_option(const char* name, int value) {
+  NEURST_CHECK_ARG(name, "set_option: null name");
+  if (!strcmp(name, "gemm256")) g_opt_gemm256 = value;
+  else if (!strcmp(name, "gemm256_min_tiles")) g_opt_gemm256_min_tiles = value;
+  else if (!strcmp(name, "gemm256_bn")) g_opt_gemm256_bn = value;
+  else if (!strcmp(name, "gemm256_ablate")) g_opt_gemm256_ablate = value;
+  else { neurst_set_error("set_option: unknown option '%s'", name); return NEURST_E_INVALID; }
+  return NEURST_OK;
+}
 static int fill_gemm_args(GemmArgs& g, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                           int64_t ldc, int ab_dtype, int c_dtype) {
   NEURST_CHECK_ARG(A && B && C, "gemm: null operand");
@@ -600,6 +615,14 @@ extern "C" int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, fl
   hipStream_t s = as_stream(stream);
   if (ab_dtype == NEURST_BF16) {
     const bool fast = g.a_aligned && g.b_aligned && K % 8 == 0 && M % 8 == 0 && N % 8 == 0;
+    // long reductions (K = rows of the batch): whole-K 256 x 256 tiles, one workgroup each, no split-K and no atomics on C
+    // (split_k is a hint: the sum is the same); few workgroups per launch, meant to run beside other launches
+    if (fast && sum_operand == 1 && use_gemm256() && g_opt_gemm256_min_tiles <= 1 && neurst_gemm256_eligible(g, 1, 0, true)) {
+      g.split_k = 1;
+      neurst_gemm256_launch(g, 1, 0, NEURST_F32, s);
+      NEURST_CHECK_LAUNCH("gemm256_wgrad");
+      return NEURST_OK;
+    }
     if (fast) launch_wgrad<bf16_t, true>(g, sum_operand, s); else launch_wgrad<bf16_t, false>(g, sum_operand, s);
   } else {
     launch_wgrad<float, false>(g, sum_operand, s);
@@ -608,21 +631,37 @@ extern "C" int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, fl
   return NEURST_OK;
 }
 
-// run-time switches (tests and A/B timing run both kernels in one process); initialised from the environment
-static int g_opt_gemm256 = [] { const char* e = getenv("NEURST_GEMM256"); return e ? atoi(e) : 1; }();
-int g_opt_gemm256_bn = 0;
-int g_opt_gemm256_ablate = 0;
-int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TILES"); return e ? atoi(e) : 128; }();
-static bool use_gemm256() { return g_opt_gemm256 != 0; }
-extern "C" int neurst_set_option(const char* name, int value) {
-  NEURST_CHECK_ARG(name, "set_option: null name");
-  if (!strcmp(name, "gemm256")) g_opt_gemm256 = value;
-  else if (!strcmp(name, "gemm256_min_tiles")) g_opt_gemm256_min_tiles = value;
-  else if (!strcmp(name, "gemm256_bn")) g_opt_gemm256_bn = value;
-  else if (!strcmp(name, "gemm256_ablate")) g_opt_gemm256_ablate = value;
-  else { neurst_set_error("set_option: unknown option '%s'", name); return NEURST_E_INVALID; }
+extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bias, const void* relu_src, int64_t M,
+                                    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
+                                    int ab_dtype, int c_dtype, int relu, int accumulate, int split_k, void* stream);
+// Several weight (+ bias) gradients of `dense` layers in one launch (autodiff of st/models/tools/utils.py:367-398 for the
+// layers of one or two Transformer blocks): problem i is C_i[M_i,N_i] += A_i^T . B_i, A_i [K_i,M_i] = dY, B_i [K_i,N_i] = X,
+// opsum_i (may be NULL) += column sums of A_i.  bf16 operands, fp32 C.
+extern "C" int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const void* const* B, float* const* C, float* const* opsum,
+                                              const int64_t* M, const int64_t* N, const int64_t* K, const int64_t* lda, const int64_t* ldb,
+                                              const int64_t* ldc, int ab_dtype, void* stream) {
+  NEURST_CHECK_ARG(n >= 1 && n <= 8 && A && B && C && opsum && M && N && K && lda && ldb && ldc, "gemm_wgrad_bias_grouped: 1 to 8 problems");
+  GemmArgs gs[8];
+  for (int i = 0; i < n; ++i) {
+    NEURST_CHECK_ARG(lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i], "gemm_wgrad_bias_grouped: leading dimension too small (problem %d)", i);
+    int rc = fill_gemm_args(gs[i], A[i], B[i], C[i], M[i], N[i], K[i], lda[i], ldb[i], ldc[i], ab_dtype, NEURST_F32);
+    if (rc) return rc;
+    gs[i].accumulate = 1; gs[i].split_k = 1; gs[i].opsum = opsum[i];
+  }
+  hipStream_t s = as_stream(stream);
+  if (ab_dtype == NEURST_BF16 && use_gemm256() && neurst_gemm256_group_launch(n, gs, s)) {
+    NEURST_CHECK_LAUNCH("gemm256_group");
+    return NEURST_OK;
+  }
+  for (int i = 0; i < n; ++i) {                                // one launch per gradient (fp32 parity mode, odd shapes)
+    int rc;
+    if (opsum[i]) rc = neurst_gemm_wgrad_bias(A[i], B[i], C[i], opsum[i], 1, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], ab_dtype, 1, stream);
+    else rc = neurst_gemm_bias_act(A[i], B[i], C[i], nullptr, nullptr, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], 1, 0, ab_dtype, NEURST_F32, 0, 1, 1, stream);
+    if (rc) return rc;
+  }
   return NEURST_OK;
 }
+
 extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bias, const void* relu_src, int64_t M,
                                     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
                                     int ab_dtype, int c_dtype, int relu, int accumulate, int split_k, void* stream) {
@@ -644,6 +683,7 @@ extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const
     // FAST: direct-to-LDS staging needs 16-byte aligned rows and whole 8-element chunks along every contiguous axis
     const bool fast = g.a_aligned && g.b_aligned && K % 8 == 0 && (!trans_a || M % 8 == 0) && (trans_b || N % 8 == 0);
     if (fast && use_gemm256() && neurst_gemm256_eligible(g, trans_a, trans_b, c_dtype == NEURST_F32)) {
+      g.split_k = 1;                                           // a hint only: C += A . B is the same sum
       neurst_gemm256_launch(g, trans_a, trans_b, c_dtype, s);
       NEURST_CHECK_LAUNCH("gemm256");
       return NEURST_OK;

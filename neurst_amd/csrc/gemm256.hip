@@ -185,14 +185,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI],
 // NI1 = MFMA tiles (16 columns each) per wave in the SECOND B piece: 2 -> 256-column output tiles, 1 -> 192-column tiles
 // (wave tile 128 x 48; M = 16000 rows give 63 tile rows, so tile counts that are multiples of 4 per tile row fill 256 CUs
 // in whole rounds: N = 768 -> 252 tiles, 2304 -> 756, 1536 -> 504).
-template <typename TC, bool TA, bool TBK, int NI1 = 2, bool STAMPS = false, int ABL = 0>
-__global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
+template <typename TC, bool TA, bool TBK, int NI1, bool STAMPS, int ABL, bool SUMA>
+__device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int block, const int G, unsigned long long* const stamps_buf) {
   constexpr bool AKS = TA, BKS = !TBK;                         // operand is k-strided in memory
   constexpr int NI = 2 + NI1, WN = 16 * NI, BNT = 4 * WN;      // MFMA tiles / columns per wave, columns per output tile
   // loads per thread of the four piece kinds (a K-contiguous second B piece of 64 rows is ONE issue)
   constexpr int NL2 = (NI1 == 1 && !BKS) ? 1 : 2;
   constexpr int NLOAD[4] = {2, 2, NL2, 2};
-  const GemmArgs& g = args.g;
   __shared__ __attribute__((aligned(16))) char smem[RING_BYTES + EPI_BYTES];   // ONE LDS object
   bf16_t* const ring = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -201,13 +200,12 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
   float* const Cs = reinterpret_cast<float*>(smem + RING_BYTES) + wave * 16 * PEPI_LD;
   const bf16_t* const A = reinterpret_cast<const bf16_t*>(g.A);
   const bf16_t* const B = reinterpret_cast<const bf16_t*>(g.B);
-  const int nk = args.nk;
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_cp)smem;      // LDS byte address of the ring
 
   // ---- static tile schedule (as gemm_persist_kernel): in every full round each XCD's workgroups take a contiguous run of
   // the grouped tile order, the last partial round is dealt evenly to the XCDs
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int G = gridDim.x, per_xcd = G >> 3;
+  const int xcd = block & 7, loc = block >> 3;
+  const int per_xcd = G >> 3;
   const int ntiles = g.tiles_m * g.tiles_n;
   const int full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
   const int rq = rem >> 3, rr8 = rem & 7;
@@ -227,15 +225,15 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
     n0 = (int64_t)((t % per_group) / gsz) * BNT;
   };
   if (tile_at(0) < 0) return;                                  // whole workgroup: nothing to do
-  unsigned long long* const stamp = STAMPS ? args.stamps + (size_t)blockIdx.x * 24 : nullptr;
+  unsigned long long* const stamp = STAMPS ? stamps_buf + (size_t)block * 24 : nullptr;
   auto put = [&](int i) __attribute__((always_inline)) {
     if constexpr (STAMPS) {
-      if (!args.stamps) return;
+      if (!stamps_buf) return;
       const unsigned long long t = clk();
       if (tid == 0 && i < 24) stamp[i] = t;
     }
   };
-  if constexpr (STAMPS) { if (tid == 0 && args.stamps) stamp[23] = __builtin_amdgcn_s_memrealtime(); }
+  if constexpr (STAMPS) { if (tid == 0 && stamps_buf) stamp[23] = __builtin_amdgcn_s_memrealtime(); }
   put(0);
 
   // ---- per-thread source offsets of the four piece kinds
@@ -323,6 +321,12 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
   put(1);
   f32x4 acc[8][NI];
   bf16x8 af[4][2], b0[2][2], b1[NI1][2];
+  // SUMA (weight gradients): opsum[m] += sum_k A[k][m], the bias gradient of the layer.  The A fragments of a duty K-tile
+  // are multiplied once more, as the B operand, against a selector whose only non-zero row is the fragment's own index:
+  // ONE accumulator tile collects the column sums of all 8 fragments (row t = sums of fragment t).  K-tiles are dealt
+  // round-robin to the 4 wave columns and to the tiles of a tile row, so every A element is summed exactly once.
+  f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+  bool duty = false;
 
   // 4 x NB x 2 MFMAs of one phase with the two DMA issues of piece `kind` spread among them: the issue of an LDS-DMA
   // instruction takes 60-180 cycles of the wave, which are hidden here behind the matrix pipe instead of lengthening the
@@ -345,6 +349,19 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
             issue1(kind, slot, ks);
             __builtin_amdgcn_sched_barrier(0);
           }
+        }
+      }
+    }
+    if constexpr (SUMA && NO == 0) {                           // phases 0 and 3: each half of the A rows exactly once
+      if (duty) {
+        const unsigned one2 = 0x3F803F80u;                     // two bf16 ones
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const unsigned w = (lane & 15) == MO + mi ? one2 : 0u;
+          const u32x4 selw = {w, w, w, w};
+          const bf16x8 sel = __builtin_bit_cast(bf16x8, selw);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, af[mi][ks], sacc, 0, 0, 0);
         }
       }
     }
@@ -430,9 +447,23 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     put(2 + round * 4);
+    const int tn_idx = (int)(n0 / BNT);
     for (int kt = 0; kt < nk; kt += 2) {                       // nk is even (an odd count is padded with an all-zero K-tile)
+      if constexpr (SUMA) duty = g.opsum && (kt & 3) == wc && (kt >> 2) % g.tiles_n == tn_idx;
       ktile(std::integral_constant<int, 0>{});
+      if constexpr (SUMA) duty = g.opsum && ((kt + 1) & 3) == wc && ((kt + 1) >> 2) % g.tiles_n == tn_idx;
       ktile(std::integral_constant<int, 1>{});
+    }
+    if constexpr (SUMA) {
+      // row t of the selector product = column sums of A fragment t: lanes 0..31 hold rows 0..7 (row = 4 (lane >> 4) + reg)
+      if (lane < 32 && g.opsum) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m0 + wr * 128 + (4 * (lane >> 4) + r) * 16 + (lane & 15);
+          if (m < g.M && sacc[r] != 0.f) atomicAdd(g.opsum + m, sacc[r]);
+        }
+      }
+      sacc = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     put(3 + round * 4);
     // ---- epilogue of this tile; the next tile's first pieces are already in flight
@@ -451,7 +482,31 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // pieces issued past the last tile (out of range: no data)
   if (wr == 0) __builtin_amdgcn_s_barrier();                   // balance the stagger
-  if constexpr (STAMPS) { put(21); if (tid == 0 && args.stamps) stamp[22] = __builtin_amdgcn_s_memrealtime(); }
+  if constexpr (STAMPS) { put(21); if (tid == 0 && stamps_buf) stamp[22] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+template <typename TC, bool TA, bool TBK, int NI1 = 2, bool STAMPS = false, int ABL = 0, bool SUMA = false>
+__global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
+  body<TC, TA, TBK, NI1, STAMPS, ABL, SUMA>(args.g, args.nk, blockIdx.x, gridDim.x, args.stamps);
+}
+
+// Several weight gradients in ONE launch: C_i[M_i, N_i] += A_i^T . B_i with A_i [K_i][M_i] (dY), B_i [K_i][N_i] (X), fp32 C,
+// opsum_i (may be null) += column sums of A_i.  Every 256 x 192 tile of every problem is one workgroup that runs the whole
+// reduction (no split-K, no atomics on C): a single gradient has 12-48 tiles, a group is packed to fill the 256 CUs.
+constexpr int MAX_GROUP = 8;
+struct GroupArgs {
+  GemmArgs gp[MAX_GROUP];
+  int nk[MAX_GROUP];
+  int first[MAX_GROUP + 1];   // first workgroup of each problem
+  int nprob;
+};
+__global__ void __launch_bounds__(NT, 2) gemm256_group_kernel(GroupArgs ga) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_GROUP; ++i)
+    if (i < ga.nprob && (int)blockIdx.x >= ga.first[i]) pi = i;
+  const int tiles = ga.first[pi + 1] - ga.first[pi];
+  body<float, true, false, 1, false, 0, true>(ga.gp[pi], ga.nk[pi], (int)blockIdx.x - ga.first[pi], (tiles + 7) & ~7, nullptr);
 }
 
 }  // namespace t2
@@ -464,7 +519,10 @@ extern int g_opt_gemm256_bn;                                 // 0 = choose per p
 static int t2_min_tiles() { return g_opt_gemm256_min_tiles; }
 // Column width of the output tile: 256 or 192.  Cost model (measured, tools/exp/gemm256_driver): a round of 256-wide tiles
 // costs its K loop plus a fixed ~15 % (epilogue, seam); a 192-wide tile 3/4 of that; the chip works in rounds of 256 tiles.
-static int t2_pick_bn(const GemmArgs& g) {
+static int t2_pick_bn(const GemmArgs& g, int trans_a) {
+  // k-strided A (weight gradients): the transposing LDS reads need more address registers, and the 256-wide body then
+  // spills inside the K loop (a scratch reload drains the operand ring): 192 columns always
+  if (trans_a) return 192;
   if (g_opt_gemm256_bn == 192 || g_opt_gemm256_bn == 256) return g_opt_gemm256_bn;
   const int64_t tm = cdiv64(g.M, t2::BM);
   double best = 0;
@@ -477,17 +535,17 @@ static int t2_pick_bn(const GemmArgs& g) {
   return pick;
 }
 bool neurst_gemm256_eligible(const GemmArgs& g, int trans_a, int trans_b, bool c_f32) {
-  if (g.split_k != 1 || g.opsum) return false;
+  if (g.opsum && !(trans_a && !trans_b && c_f32)) return false;   // operand sums: weight gradients (A = dY [K][M]) only
   if (!g.a_aligned || !g.b_aligned || g.K % 8 || (trans_a && g.M % 8) || (!trans_b && g.N % 8)) return false;
-  const int64_t tm = cdiv64(g.M, t2::BM), tn = cdiv64(g.N, t2_pick_bn(g));
+  const int64_t tm = cdiv64(g.M, t2::BM), tn = cdiv64(g.N, t2_pick_bn(g, trans_a));
   if (tm * tn < t2_min_tiles()) return false;
   // Where it wins over the 128 x 128 kernels (tools/exp/gemm256_driver, M = 16000): an output tile costs ~10k cycles of
   // epilogue (all workgroups store at once: HBM-write bound) plus ~3300 cycles per K-tile, so long K loops pay - K = 3072
   // x1.13 (NT), K = 10000 x1.46 - and so does the fp32 vocabulary projection (x1.10); at K = 768 the 128-tile kernels,
   // whose co-resident workgroups hide each other's stores, stay ahead (x0.75-0.95).  min_tiles <= 1 (tests, drivers) lifts the rule.
   if (t2_min_tiles() > 1) {
-    const bool long_k = (g.K >= 2560 && trans_b && !trans_a) || g.K >= 8192;
-    const bool wide_f32 = c_f32 && g.N >= 4096;
+    const bool long_k = !trans_a && ((g.K >= 2560 && trans_b) || g.K >= 8192);   // (weight gradients: grouped launches only)
+    const bool wide_f32 = c_f32 && g.N >= 4096 && !trans_a;
     if (!long_k && !wide_f32) return false;
   }
   // 32-bit offsets inside one (tile, K-tile) window
@@ -525,13 +583,41 @@ static void launch256(const GemmArgs& g0, int trans_a, int trans_b, hipStream_t 
       }
     }
   }
+  if constexpr (sizeof(TC) == 4) {
+    if (g0.opsum) { t2::gemm256_kernel<TC, true, false, NI1, false, 0, true><<<grid, t2::NT, 0, s>>>(a); return; }
+  }
   if (!trans_a && trans_b) t2::gemm256_kernel<TC, false, true, NI1><<<grid, t2::NT, 0, s>>>(a);
   else if (!trans_a && !trans_b) t2::gemm256_kernel<TC, false, false, NI1><<<grid, t2::NT, 0, s>>>(a);
   else if (trans_a && !trans_b) t2::gemm256_kernel<TC, true, false, NI1><<<grid, t2::NT, 0, s>>>(a);
   else t2::gemm256_kernel<TC, true, true, NI1><<<grid, t2::NT, 0, s>>>(a);
 }
 void neurst_gemm256_launch(const GemmArgs& g, int trans_a, int trans_b, int c_dtype, hipStream_t s) {
-  const bool wide = t2_pick_bn(g) == 256;
+  const bool wide = t2_pick_bn(g, trans_a) == 256;
   if (c_dtype == NEURST_BF16) { if (wide) launch256<bf16_t, 2>(g, trans_a, trans_b, s); else launch256<bf16_t, 1>(g, trans_a, trans_b, s); }
   else { if (wide) launch256<float, 2>(g, trans_a, trans_b, s); else launch256<float, 1>(g, trans_a, trans_b, s); }
+}
+
+// Grouped weight gradients (see t2::gemm256_group_kernel).  Host arrays of n <= 8 problems; returns false when a problem
+// does not fit the kernel (alignment, 32-bit window) - the caller then falls back to one launch per gradient.
+bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, hipStream_t s) {
+  if (n < 1 || n > t2::MAX_GROUP) return false;
+  t2::GroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& g = probs[i];
+    if (!g.a_aligned || !g.b_aligned || g.M % 8 || g.N % 8) return false;
+    if ((64 * g.lda + 256) * 2 >= 0x7fff0000ll || (64 * g.ldb + 256) * 2 >= 0x7fff0000ll) return false;
+    ga.gp[i] = g;
+    ga.gp[i].tiles_m = (int)cdiv64(g.M, t2::BM);
+    ga.gp[i].tiles_n = (int)cdiv64(g.N, 192);
+    ga.gp[i].split_k = 1;
+    ga.nk[i] = (int)((cdiv64(g.K, t2::BK) + 1) / 2 * 2);
+    ga.first[i] = total;
+    total += ga.gp[i].tiles_m * ga.gp[i].tiles_n;
+  }
+  ga.first[n] = total;
+  ga.nprob = n;
+  t2::gemm256_group_kernel<<<total, t2::NT, 0, s>>>(ga);
+  return true;
 }

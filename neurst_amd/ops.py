@@ -6,6 +6,8 @@ import math
 import os
 
 import numpy as np
+import ctypes
+
 import torch
 
 from . import lib as _lib
@@ -203,6 +205,24 @@ def gemm_wgrad_bias(A, B, C, opsum, sum_operand, M, N, K, lda, ldb, ldc, split_k
                                    _DT[A.dtype], split_k, _override_raw or _raw_stream(_cur_dev()))
     if rc:
         _lib.check(rc, 'gemm_wgrad_bias')
+
+
+def gemm_wgrad_grouped(problems):
+    """[(A [K, M] = dY, B [K, N] = X, C [M, N] fp32, opsum [M] fp32 or None), ...] (at most 8): C += A^T . B and
+    opsum += column sums of A for every problem in one launch (neurst_gemm_wgrad_bias_grouped)."""
+    n = len(problems)
+    P = ctypes.c_void_p * n
+    L = ctypes.c_int64 * n
+    A = P(*[a.data_ptr() for a, _, _, _ in problems])
+    B = P(*[b.data_ptr() for _, b, _, _ in problems])
+    C = P(*[c.data_ptr() for _, _, c, _ in problems])
+    S = P(*[(o.data_ptr() if o is not None else None) for _, _, _, o in problems])
+    M = L(*[a.shape[1] for a, _, _, _ in problems])
+    N = L(*[b.shape[1] for _, b, _, _ in problems])
+    K = L(*[a.shape[0] for a, _, _, _ in problems])
+    rc = _C.neurst_gemm_wgrad_bias_grouped(n, A, B, C, S, M, N, K, M, N, N, _DT[problems[0][0].dtype], _override_raw or _raw_stream(_cur_dev()))
+    if rc:
+        _lib.check(rc, 'gemm_wgrad_bias_grouped')
 
 
 def colsum(x2d, out, accumulate=True):

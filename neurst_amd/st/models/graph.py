@@ -219,6 +219,15 @@ class Graph:
         self.side_used = False
         self.in_early = False
         self.side_writes = set()
+        # Encoder-size weight gradients (thousands of rows) are not launched one by one: each has only 12-48 output tiles
+        # of 256 x 192, and the whole-K tile kernel runs one workgroup per tile.  They are collected until their tiles fill
+        # the 256 CUs and go out as ONE grouped launch (ops.gemm_wgrad_grouped) on the weight-gradient stream.
+        # NEURST_GROUP_WGRAD=0 turns it off (one split-K launch per gradient).
+        self.group_wgrads = os.environ.get('NEURST_GROUP_WGRAD', '1') != '0'
+        self.group_min_rows = 8192
+        self.pending_wgrads = []
+        self.pending_tiles = 0
+        self.pending_reads = set()
 
     @contextlib.contextmanager
     def variable_scope(self, name):
@@ -344,9 +353,59 @@ class Graph:
             if p in self.side_reads:
                 self.before_inplace_write(t)
 
+    # ---- grouped weight gradients ----------------------------------------------------------------------------
+    def defer_wgrad(self, dy2, x2, w, layout, bias):
+        """Take the weight (+ bias) gradient of one dense layer into the pending group; False = not a case for the grouped
+        kernel (the caller launches it the usual way).  param_grad_done is reported when the group is launched."""
+        M = x2.shape[0]
+        if (not self.group_wgrads or dy2.device.type != 'cuda' or dy2.dtype != torch.bfloat16 or M < self.group_min_rows
+                or not dy2.is_contiguous() or not x2.is_contiguous()):
+            return False
+        if layout == 'out_in':
+            a, b = dy2, x2                      # grad[n_out, n_in] += dy^T . x, bias.grad += column sums of dy
+        elif bias is None:
+            a, b = x2, dy2                      # grad[n_in, n_out] += x^T . dy
+        else:
+            return False
+        rows, cols = a.shape[1], b.shape[1]
+        tiles = -(-rows // 256) * -(-cols // 192)
+        if tiles > 64 or rows % 8 or cols % 8:
+            return False
+        if self.pending_wgrads and (self.pending_tiles + tiles > 256 or len(self.pending_wgrads) == 8):
+            self.flush_wgrads()
+        self.pending_wgrads.append((a, b, w, bias if layout == 'out_in' else None, bias))
+        self.pending_tiles += tiles
+        self.pending_reads.add(a.untyped_storage().data_ptr())
+        self.pending_reads.add(b.untyped_storage().data_ptr())
+        if self.pending_tiles >= 236:
+            self.flush_wgrads()
+        return True
+
+    def flush_wgrads(self):
+        """Launch the pending group (on the weight-gradient stream when there is one) and report its parameters done."""
+        group, self.pending_wgrads, self.pending_tiles = self.pending_wgrads, [], 0
+        self.pending_reads.clear()
+        if not group:
+            return
+        K = group[0][0].shape[0]
+        side = self.side_stream_for(K, group[0][0].device)
+
+        def launch():
+            ops.gemm_wgrad_grouped([(a, b, w.grad, (bs.grad if bs is not None else None)) for a, b, w, bs, _ in group])
+        if side is not None:
+            self.run_on_side(side, launch, *[t for a, b, _, _, _ in group for t in (a, b)])
+        else:
+            launch()
+        for _, _, w, _, bias in group:
+            self.param_grad_done(w)
+            if bias is not None:
+                self.param_grad_done(bias)
+
     def before_inplace_write(self, t):
         """Main-stream kernels are about to update `t` in place: if a side-stream kernel may still read that storage,
         wait for the side stream's tail (covers every reader enqueued so far)."""
+        if self.pending_reads and t.untyped_storage().data_ptr() in self.pending_reads:
+            self.flush_wgrads()                 # a gradient still waiting for its group reads this tensor: launch it first
         if self.side_reads and t.untyped_storage().data_ptr() in self.side_reads:
             ev = torch.cuda.Event()
             ev.record(self.wgrad_stream)
@@ -355,6 +414,7 @@ class Graph:
 
     def join_side_streams(self):
         """Everything enqueued on the side stream happens-before what the current stream does next (Adam, all-reduce wait)."""
+        self.flush_wgrads()
         if self.side_used:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self.side_used = False

@@ -80,14 +80,17 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient, early_b
             if dy2.dtype != x2.dtype:
                 raise TypeError('gradient dtype {} does not match operand dtype {}'.format(dy2.dtype, x2.dtype))
             bw = None if (hook is not None and hook.taken) else b
-            side = g.side_stream_for(M, dy2.device)
-            if side is not None:     # small layer: weight (and bias) gradient beside the data-gradient chain
-                g.run_on_side(side, lambda: _wgrad(dy2, x2, w, layout, bw), dy2, x2)
+            if bw is b and g.defer_wgrad(dy2, x2, w, layout, b):
+                pass                 # encoder-size layer: goes out with its group (graph.flush_wgrads reports the parameters)
             else:
-                _wgrad(dy2, x2, w, layout, bw)
-            g.param_grad_done(w)
-            if b is not None:
-                g.param_grad_done(b)
+                side = g.side_stream_for(M, dy2.device)
+                if side is not None:     # small layer: weight (and bias) gradient beside the data-gradient chain
+                    g.run_on_side(side, lambda: _wgrad(dy2, x2, w, layout, bw), dy2, x2)
+                else:
+                    _wgrad(dy2, x2, w, layout, bw)
+                g.param_grad_done(w)
+                if b is not None:
+                    g.param_grad_done(b)
             if not stop_gradient:
                 have = tape.has(inputs)
                 dx = tape.grad(inputs) if have else torch.empty_like(inputs)

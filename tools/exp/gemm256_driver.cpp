@@ -142,6 +142,93 @@ int main(int argc, char** argv) {
     }
     neurst_set_option("gemm256_bn", 0);
   }
+  if (!strcmp(mode, "wgrad") || !strcmp(mode, "all")) {
+    // weight gradient + bias gradient: whole-K 256 x 192 tiles (few workgroups, no split-K) against the 128-tile split-K kernel
+    struct W { const char* name; int64_t M, N, K; int sk; };
+    std::vector<W> ws = {{"wgrad qkv", 2304, 768, 16000, 4}, {"wgrad out", 768, 768, 16000, 8}, {"wgrad ffn1", 3072, 768, 16000, 3},
+                         {"wgrad ffn2", 768, 3072, 16000, 3}, {"wgrad ragged", 776, 520, 1000, 2}};
+    float* opsum0; float* opsum1; CK(hipMalloc(&opsum0, 65536 * 4)); CK(hipMalloc(&opsum1, 65536 * 4));
+    {
+      std::vector<unsigned short> h(1 << 22);
+      unsigned s = 4242;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = f2bf((float)((int)((s >> 20) % 5) - 2)); }
+      for (size_t off = 0; off < maxe; off += h.size()) {
+        size_t n = maxe - off < h.size() ? maxe - off : h.size();
+        CK(hipMemcpy((char*)A + off * 2, h.data(), n * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy((char*)B + off * 2 , h.data() + 3, (n - 3) * 2, hipMemcpyHostToDevice));
+      }
+    }
+    neurst_set_option("gemm256_min_tiles", 1);
+    for (auto& w : ws) {
+      void* Cs[2] = {C0, C1}; float* os[2] = {opsum0, opsum1};
+      for (int which = 0; which < 2; ++which) {
+        neurst_set_option("gemm256", which);
+        for (int rep = 0; rep < (which ? 2 : 1); ++rep) {
+          CK(hipMemset(Cs[which], 0, w.M * w.N * 4)); CK(hipMemset(os[which], 0, w.M * 4));
+          int rc = neurst_gemm_wgrad_bias(A, B, (float*)Cs[which], os[which], 1, w.M, w.N, w.K, w.M, w.N, w.N, NEURST_BF16, w.sk, nullptr);
+          if (rc) { printf("wgrad error %s\n", neurst_last_error()); return 1; }
+          CK(hipDeviceSynchronize());
+          if (which) {
+            std::vector<float> h0(w.M * w.N), h1(w.M * w.N), o0(w.M), o1(w.M);
+            CK(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(o0.data(), opsum0, w.M * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), opsum1, w.M * 4, hipMemcpyDeviceToHost));
+            size_t nd = 0, ns = 0;
+            for (size_t i = 0; i < h0.size(); ++i) nd += h0[i] != h1[i];
+            for (size_t i = 0; i < o0.size(); ++i) ns += o0[i] != o1[i];
+            printf("%-14s rep %d: C %s (%zu differ), bias sums %s (%zu differ; e.g. %g vs %g)\n", w.name, rep, nd ? "MISMATCH" : "ok", nd, ns ? "MISMATCH" : "ok", ns,
+                   o0[5], o1[5]);
+            if (nd || ns) ++bad;
+          }
+        }
+      }
+    }
+    // timing on random operands: one launch alone, and the four gradients of an encoder block on four streams at once
+    {
+      std::vector<unsigned short> h(1 << 24);
+      unsigned s = 12345;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 16) & 0x807f) | 0x3f00 | ((s >> 9) & 0x0080)); }
+      for (size_t off = 0; off + h.size() <= maxe; off += h.size()) {
+        CK(hipMemcpy((char*)A + off * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy((char*)B + off * 2, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+      }
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipStream_t st[4]; for (auto& x : st) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    for (int which = 0; which < 2; ++which) {
+      neurst_set_option("gemm256", which);
+      for (int wi = 0; wi < 4; ++wi) {
+        auto& w = ws[wi];
+        float best = 1e9;
+        for (int round = 0; round < 3; ++round) {
+          CK(hipEventRecord(e0, st[0]));
+          for (int i = 0; i < 5; ++i) neurst_gemm_wgrad_bias(A, B, (float*)C0, opsum0, 1, w.M, w.N, w.K, w.M, w.N, w.N, NEURST_BF16, w.sk, st[0]);
+          CK(hipEventRecord(e1, st[0])); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms / 5 < best) best = ms / 5;
+        }
+        printf("%s %-12s alone: %8.1f us  %7.1f TF/s\n", which ? "256x192 whole-K" : "128-tile split-K", w.name, best * 1e3, 2.0 * w.M * w.N * w.K / best / 1e9);
+      }
+      // a block's four gradients, 4 rounds: serial on one stream vs one stream per gradient
+      for (int conc = 0; conc < 2; ++conc) {
+        float best = 1e9;
+        for (int round = 0; round < 3; ++round) {
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(e0, st[0]));
+          for (int x = 1; x < 4; ++x) { hipEvent_t ev; CK(hipEventCreate(&ev)); CK(hipEventRecord(ev, st[0])); CK(hipStreamWaitEvent(st[x], ev, 0)); CK(hipEventDestroy(ev)); }
+          for (int i = 0; i < 4; ++i)
+            for (int wi = 0; wi < 4; ++wi) {
+              auto& w = ws[wi];
+              neurst_gemm_wgrad_bias(A, B, (float*)C0 + (size_t)wi * 3072 * 3072, opsum0 + wi * 4096, 1, w.M, w.N, w.K, w.M, w.N, w.N, NEURST_BF16, w.sk, st[conc ? wi : 0]);
+            }
+          for (int x = 1; x < 4; ++x) { hipEvent_t ev; CK(hipEventCreate(&ev)); CK(hipEventRecord(ev, st[x])); CK(hipStreamWaitEvent(st[0], ev, 0)); CK(hipEventDestroy(ev)); }
+          CK(hipEventRecord(e1, st[0])); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        const double fl = 4 * 2.0 * 16000 * (2304.0 * 768 + 768.0 * 768 + 2 * 3072.0 * 768);
+        printf("%s, 4 blocks x 4 gradients, %s: %8.1f us  %7.1f TF/s\n", which ? "256x192 whole-K" : "128-tile split-K", conc ? "four streams" : "one stream", best * 1e3,
+               fl / best / 1e9);
+      }
+    }
+  }
   if (!strcmp(mode, "ablate")) {
     // timing-only builds of the K loop (results are wrong): which part of a phase sets its length?
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
