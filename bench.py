@@ -12,6 +12,7 @@ Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -39,13 +40,32 @@ def lut_step_flops(B, T, L, Lb, V, d=768, din=480, nenc=4, nenc2=4, ndec=4):
     return fwd, 3 * fwd
 
 
-def pmc_traffic(kernel_label):
+def kernel_sources_digest():
+    """sha256 over the kernel sources the library is built from: counters collected for one build say nothing about another"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'neurst_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_label, tag):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md 'HBM'); None if not collected."""
-    path = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+    (profiles/<tag>_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md 'HBM').  The file records the digest
+    of the kernel sources it was collected for; when that differs from the tree this run was built from, the figure is
+    stale and is NOT reported (traffic = null, traffic_stale = true)."""
+    path = os.path.join(ROOT, 'profiles', tag + '_hbm_traffic.json')
+    info = {'traffic_source': 'profiles/%s_hbm_traffic.json' % tag, 'traffic_stale': None, 'traffic_sources_digest': None}
     if not os.path.exists(path):
-        return None
-    return json.load(open(path)).get('bytes_per_launch', {}).get(kernel_label)
+        return None, info
+    d = json.load(open(path))
+    info['traffic_sources_digest'] = d.get('kernel_sources_digest')
+    info['traffic_stale'] = d.get('kernel_sources_digest') != kernel_sources_digest()
+    val = d.get('bytes_per_launch', {}).get(kernel_label)
+    return (None if info['traffic_stale'] else val), info
 
 
 class KernelTimer:
@@ -85,6 +105,20 @@ class KernelTimer:
             timer.records.setdefault(ops.gemm_kernel_label(A, C, M, N, K, True, False, kw.get('split_k', 1), True), []).append((e0, e1, 2.0 * M * N * K))
             return r
         ops.gemm_wgrad_bias = gemm_wgrad_bias
+        orig_g = ops.gemm_wgrad_grouped
+
+        def gemm_wgrad_grouped(problems):
+            if not timer.enabled:
+                return orig_g(problems)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = ops.active_stream()
+            e0.record(st)
+            r = orig_g(problems)
+            e1.record(st)
+            fl = sum(2.0 * a_.shape[1] * b_.shape[1] * a_.shape[0] for a_, b_, _, _ in problems)
+            timer.records.setdefault('gemm256_group_kernel', []).append((e0, e1, fl))
+            return r
+        ops.gemm_wgrad_grouped = gemm_wgrad_grouped
 
     def summary(self):
         out = {}
@@ -97,29 +131,60 @@ class KernelTimer:
 
 
 def cpu_baseline(threads):
-    """The numpy fp32 oracle (a PORT of the reference graph - TF 1.15 cannot run here) on a bounded sample
-    of the same workload: LUT widths, B=8 x 1000 raw frames (T=334, BASELINE config 1), L=U=Lb=40, V=10000, mean of steps 2..7 of seven fwd+bwd+Adam steps."""
+    """The reference graph on the host cores (TF 1.15 itself cannot run here), on a bounded sample of the benchmark's own
+    workload: LUT widths at BASELINE config 2's shape with B = 8 of the 32 utterances (every op of the step is per
+    utterance, so frames/s does not depend on B beyond BLAS efficiency), T = 500, L = U = Lb = 40, V = 10000, dropout 0.
+    Two legs (SURVEY.md 8d): (i) the numpy fp32 oracle, forward + hand-written backward + Adam (`value`);
+    (ii) the same graph in torch-CPU fp32 (library ops + autograd + the same Adam arithmetic)."""
     import yaml
     from oracle.model import OracleTPE, TPEConfig, init_params, train_step
     from oracle import ops as oops
+    from oracle import torch_graph
     from neurst_amd.synthetic import make_batch
     cfg = TPEConfig.from_yaml_dict(yaml.safe_load(open(os.path.join(ROOT, 'configs', 'lut.yaml'))), 10000).zero_dropout()
-    B, Traw, Ln = 8, 1000, 40
+    B, Traw, Ln = 8, 1500, 40
     batch = make_batch(B=B, Traw=Traw, V=10000, L=Ln, U=Ln, Lb=Ln, bert_dim=768, seed=7)
     batch['feature'], batch['len_fea'] = oops.splice_downsample_batch(batch['feature'], batch['len_fea'], 5, 3)
+    T = batch['feature'].shape[1]
     P = init_params(cfg, seed=1, dtype=np.float32)
     M = {k: np.zeros_like(v) for k, v in P.items()}
     V = {k: np.zeros_like(v) for k, v in P.items()}
     model = OracleTPE(cfg, is_train=True, dropout=False)
-    nstep = 6
+    nstep = 3
     train_step(model, P, M, V, batch, 1, 50000, 4e-4, 50000)      # untimed: page in BLAS, allocate
     t0 = time.time()
     for i in range(nstep):
         train_step(model, P, M, V, batch, 2 + i, 50000, 4e-4, 50000)
     dt = (time.time() - t0) / nstep
-    T = batch['feature'].shape[1]
+    # (ii) torch-CPU
+    torch.set_num_threads(threads)
+    Pt = {k: torch.tensor(v, requires_grad=True) for k, v in init_params(cfg, seed=1, dtype=np.float32).items()}
+    Mt = {k: torch.zeros_like(v) for k, v in Pt.items()}
+    Vt = {k: torch.zeros_like(v) for k, v in Pt.items()}
+
+    def torch_step(t):
+        loss, _ = torch_graph.loss_fn(Pt, cfg, batch)
+        grads = torch.autograd.grad(loss, list(Pt.values()), allow_unused=True)
+        lr_t = 4e-4 * t / 50000 * math.sqrt(1 - 0.98 ** t) / (1 - 0.9 ** t)
+        with torch.no_grad():
+            for (k, p), g in zip(Pt.items(), grads):
+                if g is None:
+                    continue
+                Mt[k].mul_(0.9).add_(g, alpha=0.1)
+                Vt[k].mul_(0.98).addcmul_(g, g, value=0.02)
+                p.sub_(lr_t * Mt[k] / (Vt[k].sqrt() + 1e-9))
+        return float(loss.detach())
+    torch_step(1)
+    t0 = time.time()
+    for i in range(nstep):
+        torch_step(2 + i)
+    dt_t = (time.time() - t0) / nstep
     return {'value': B * T / dt, 'unit': 'encoder frames/s', 'cores': threads, 'kind': 'port',
-            'sample': 'numpy fp32 oracle (BLAS threads = cores), LUT train step at BASELINE config 1: B=%d x %d raw frames (T=%d), L=U=Lb=%d, V=10000, dropout 0; %.2f s/step over %d timed steps' % (B, Traw, T, Ln, dt, nstep)}
+            'sample': 'numpy fp32 oracle (BLAS threads = cores), LUT train step at BASELINE config 2\'s shape with B=%d of its 32 utterances: %d raw '
+                      'frames (T=%d), L=U=Lb=%d, V=10000, dropout 0; %.2f s/step over %d timed steps' % (B, Traw, T, Ln, dt, nstep),
+            'torch_cpu': {'value': B * T / dt_t, 'unit': 'encoder frames/s', 'cores': threads, 'kind': 'port',
+                          'sample': 'the same step as torch-CPU fp32 autograd (oracle/torch_graph.py) + Adam, %d threads; %.2f s/step over %d timed steps'
+                                    % (threads, dt_t, nstep)}}
 
 
 def main():
@@ -134,6 +199,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--ragged', action='store_true')
+    ap.add_argument('--profile-tag', default='r02', help='profiles/<tag>_hbm_traffic.json holds the PMC traffic of the dominant kernel')
     ap.add_argument('--bucket-mb', type=float, default=None, help='size of the gradient buckets that are all-reduced as units (default: the config value or 64)')
     ap.add_argument('--serial-streams', action='store_true',
                     help='no second HIP streams (CTC recursion, weight gradients): every kernel has the chip to itself, as in '
@@ -239,7 +305,8 @@ def main():
                 'step_algorithmic_tflop': tot / 1e12, 'step_achieved': tot / step_s / 1e12, 'step_frac': tot / step_s / 1e12 / peak}
         if kern:
             dom = max(kern, key=lambda k: kern[k]['total_ms'])
-            roof['traffic'] = pmc_traffic(dom)
+            roof['traffic'], tinfo = pmc_traffic(dom, a.profile_tag)
+            roof.update(tinfo)
             roof['kernel_timing'] = ('HIP events around each launch in %d extra steps with the second streams off (one kernel on the '
                                      'chip at a time; same mode as profiles/: bench.py --serial-streams under rocprofv3)' % ksteps)
             roof.update(kernel=dom, achieved=kern[dom]['tflops'], frac=kern[dom]['tflops'] / peak,

@@ -190,6 +190,10 @@ def gemm_kernel_label(A, C, M, N, K, trans_a, trans_b, split_k=1, bias_grad=Fals
     c = 'bf16' if C.dtype == torch.bfloat16 else 'f32'
     lay = {(False, True): 'NT', (False, False): 'NN', (True, False): 'TN', (True, True): 'TT'}[(bool(trans_a), bool(trans_b))]
     fast = ab == 'bf16' and K % 8 == 0 and (not trans_a or M % 8 == 0) and (trans_b or N % 8 == 0)
+    # csrc/gemm256.hip neurst_gemm256_eligible: long reductions and the wide fp32 result, from 128 tiles of 256 x 256 up
+    if fast and not trans_a and not bias_grad and -(-M // 256) * -(-N // 256) >= 128 and (
+            (K >= 2560 and trans_b) or K >= 8192 or (c == 'f32' and N >= 4096)):
+        return 'gemm256_kernel<bf16,%s,%s>' % (c, lay)
     tiles = -(-M // 128) * -(-N // 128) * max(split_k, 1)
     ns = 4 if (fast and tiles <= 256 and K >= 256) else 2
     if ns == 4 and not trans_a and split_k <= 1 and not bias_grad and tiles <= THIN_MAX_TILES:

@@ -45,6 +45,31 @@ class _Shard:
         return keep
 
 
+class _Control:
+    """Control-plane messages between the ranks (the early-stop decision after a dev pass).  They do not travel over the
+    gradient process group: while rank 0 decodes the dev set the other ranks would sit inside an RCCL collective and its
+    watchdog would end the job when the pass outlasts the process-group timeout.  A second, gloo group with a day-long
+    timeout carries one host integer instead; the waiting ranks hold no device collective meanwhile."""
+
+    def __init__(self, world):
+        self.world = world
+        self.group = None
+        if world > 1:
+            import datetime
+            import torch.distributed as dist
+            self.group = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=24))
+
+    def broadcast_flag(self, flag):
+        """rank 0's decision, on every rank"""
+        if self.group is None:
+            return bool(flag)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.broadcast(t, src=0, group=self.group)
+        return bool(int(t[0]))
+
+
 def build_models(args):
     gs = GlobalStep(0)
     kw = dict(encoder=args.model.encoder.type, decoder=args.model.decoder.type, args=args)
@@ -56,6 +81,7 @@ def build_models(args):
 def train(args, max_steps=None):
     """:30-455.  Returns the list of per-step losses (for tests)."""
     rank, world = _rank_world()
+    control = _Control(world)
     model, model_infer = build_models(args)
     os.makedirs(args.dir_checkpoint, exist_ok=True)
     summary = Summary(args.dir_log) if rank == 0 else None
@@ -91,11 +117,15 @@ def train(args, max_steps=None):
             bad_count += 1
 
     def dev_and_maybe_stop(global_step):
-        if rank != 0 or not (args.dirs.dev and args.dirs.dev.tfdata):
+        """every rank calls this at the same steps: rank 0 scores the dev set, all ranks learn its stop decision"""
+        if not (args.dirs.dev and args.dirs.dev.tfdata):
             return False
-        _, dev_wer, dev_bleu = evaluate_decode(global_step)
-        check_save(dev_bleu, dev_wer, global_step)
-        return bool(args.early_stop and bad_count > args.early_stop)
+        stop = False
+        if rank == 0:
+            _, dev_wer, dev_bleu = evaluate_decode(global_step)
+            check_save(dev_bleu, dev_wer, global_step)
+            stop = bool(args.early_stop and bad_count > args.early_stop)
+        return control.broadcast_flag(stop)
 
     start_time = datetime.now()
     losses, num_processed, progress = [], 0, 0.0

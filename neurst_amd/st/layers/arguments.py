@@ -4,6 +4,7 @@ None, several config files merged recursively, and the derived fields the hot pa
 The reference's import-time side effects (directory creation, vocab / CSV / tfdata
 loading, reading sys.argv) are NOT reproduced: vocabulary size and token ids are passed in.
 """
+import os
 import yaml
 
 
@@ -53,10 +54,15 @@ def build_args(config, dim_output, token2idx=None, dim_feature=None, compute_dty
         _merge(cfg, overrides)
     args = AttrDict(cfg)
     args.num_gpus = len(str(args.gpus).split(',')) if args.gpus is not None else 1
+    # The reference builds one batch for all its in-graph towers and tf.splits it (arguments.py:86-87, lstmModel.py:342-350).
+    # Here every process is ONE tower that reads whole batches of its own (run_lut._Shard), so under a multi-process launch
+    # (WORLD_SIZE set by torchrun) the per-tower size applies: a reference-style `gpus: '0,...,7'` would otherwise give
+    # every rank an 8x batch, i.e. a 64x global batch.
+    args.towers_per_batch = 1 if int(os.environ.get('WORLD_SIZE', '1')) > 1 else args.num_gpus
     args.list_gpus = ['/gpu:{}'.format(i) for i in range(args.num_gpus)]
     if args.bucket_boundaries:
         args.list_bucket_boundaries = [int(i) for i in str(args.bucket_boundaries).split(',')]
-        args.list_batch_size = [int(args.num_batch_tokens / b) * args.num_gpus for b in args.list_bucket_boundaries] + [args.num_gpus]
+        args.list_batch_size = [int(args.num_batch_tokens / b) * args.towers_per_batch for b in args.list_bucket_boundaries] + [args.towers_per_batch]
     args.token2idx = token2idx or {'<pad>': 0, '<unk>': 1, '<sos>': 2, '<eos>': 3, '<blk>': dim_output - 1}
     args.dim_output = dim_output
     args.src_dim_output = dim_output

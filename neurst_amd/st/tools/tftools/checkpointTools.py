@@ -148,8 +148,25 @@ def restore(ckpt_dir_or_file, store, assignment_map=None, slots=True, strict=Tru
         store.load_slots(m, v)
         if r.has_tensor('adam_t'):
             store.adam_t = int(r.get_tensor('adam_t'))
-        elif r.has_tensor('beta1_power'):      # a TensorFlow-written checkpoint: beta1_power = beta1^(t+1) (lstmModel.py:526-530, beta1 = 0.9)
-            store.adam_t = max(int(round(np.log(float(r.get_tensor('beta1_power'))) / np.log(0.9))) - 1, 0)
+        elif r.has_tensor('beta1_power') or r.has_tensor('beta2_power'):
+            store.adam_t = _adam_t_from_powers(r)
+    return int(r.get_tensor('global_step')) if r.has_tensor('global_step') else 0
+
+
+def _adam_t_from_powers(r):
+    """Adam's step count of a TensorFlow-written checkpoint, which stores beta1^(t+1) and beta2^(t+1) as fp32 scalars instead
+    (lstmModel.py:526-530: beta1 = 0.9, beta2 = 0.98).  0.9^t underflows to 0 in fp32 near t = 1000 and loses digits long
+    before; 0.98^t lasts to about t = 4000.  Take whichever power is still well inside the normal range, beta2's first; past
+    both, the bias corrections are 1 to fp32 precision and the checkpoint's global_step (one Adam step per train step) is
+    the count."""
+    tiny = 1e-30
+    for name, beta in (('beta2_power', 0.98), ('beta1_power', 0.9)):
+        if r.has_tensor(name):
+            x = float(r.get_tensor(name))
+            if tiny < x < 1.0:
+                return max(int(round(np.log(x) / np.log(beta))) - 1, 0)
+            if x >= 1.0:
+                return 0
     return int(r.get_tensor('global_step')) if r.has_tensor('global_step') else 0
 
 

@@ -270,7 +270,8 @@ class TFReader:
                 args.list_bucket_boundaries = [int(i) for i in str(args.bucket_boundaries).split(',')]
             else:
                 args.list_bucket_boundaries = list(range(args.size_bucket_start, args.size_bucket_end, args.size_bucket_gap))
-            args.list_batch_size = [int(args.num_batch_tokens / b) * args.num_gpus for b in args.list_bucket_boundaries] + [args.num_gpus]
+            n_tow = args.towers_per_batch or args.num_gpus or 1       # arguments.build_args: 1 per process under torchrun
+            args.list_batch_size = [int(args.num_batch_tokens / b) * n_tow for b in args.list_bucket_boundaries] + [n_tow]
         self.list_batch_size = args.list_batch_size
         self.list_bucket_boundaries = args.list_bucket_boundaries
         m = args.model

@@ -1,5 +1,6 @@
-"""Independent torch-CPU (autograd, float64) expression of the TransformerTPE train
-graph, used ONLY to cross-check the numpy oracle.  It shares no code
+"""TEST INFRASTRUCTURE (like the rest of oracle/): an independent torch-CPU (autograd) expression of the TransformerTPE train
+graph, used to cross-check the numpy oracle and, in float32, as the second leg of bench.py's cpu_baseline
+(the stand-in for "the reference TF graph on CPU" - both bottom out in multithreaded library GEMMs).  It shares no code
 with oracle/: attention, layer norm, CTC and the losses go through torch library ops
 and autograd instead of the oracle's hand-derived backward.
 """

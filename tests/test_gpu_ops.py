@@ -169,6 +169,105 @@ def test_gemm_wgrad_with_fused_bias_gradient(dtype, tol, M, N, K, split):
         assert relerr(host(s), vec.astype(np.float64).sum(0) + 2.0) < 1e-5, which
 
 
+@pytest.fixture
+def gemm256_everywhere():
+    """route every eligible bf16 problem to the 256-tile kernel (the production rule wants long K loops or a wide fp32 result)"""
+    from neurst_amd import lib
+    C = lib.load()
+    assert C.neurst_set_option(b'gemm256_min_tiles', 1) == 0
+    yield C
+    assert C.neurst_set_option(b'gemm256_min_tiles', 128) == 0 and C.neurst_set_option(b'gemm256_bn', 0) == 0 and C.neurst_set_option(b'gemm256', 1) == 0
+
+
+@pytest.mark.parametrize('bn', [256, 192])
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K,cdt', [(300, 520, 200, 'bf16'), (777, 264, 72, 'f32'), (1030, 776, 1000, 'bf16'), (2048, 768, 448, 'bf16'), (256, 256, 64, 'f32')])
+def test_gemm_256_tile_kernel(gemm256_everywhere, bn, ta, tb, M, N, K, cdt):
+    """csrc/gemm256.hip (256 x 256 / 256 x 192 output tiles, operand ring by LDS-DMA): every operand layout, ragged edges in M
+    and N, a partial and an odd number of K-tiles, bias + relu, accumulate, the relu-gradient gate, fp32 and bf16 results,
+    against numpy in fp64 and - on small-integer operands, where every partial sum is exact - bit for bit against the
+    128 x 128 kernels; three launches each (a wait placed one piece early would show as a rare wrong tile)."""
+    Clib = gemm256_everywhere
+    assert Clib.neurst_set_option(b'gemm256_bn', bn) == 0
+    rng = np.random.default_rng(M + K + bn)
+    A = bf16_round(rng.standard_normal((K, M) if ta else (M, K)))
+    B = bf16_round(rng.standard_normal((N, K) if tb else (K, N)))
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    tc = torch.bfloat16 if cdt == 'bf16' else torch.float32
+    tol = 1e-2 if cdt == 'bf16' else 1e-5
+    dA, dB = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    for rep in range(3):
+        C = torch.full((M, N), float('nan'), dtype=tc, device=DEV)
+        ops.gemm(dA, dB, C, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias))
+        assert relerr(host(C), ref + bias) < tol, rep
+    C2 = torch.full((M, N), 0.5, dtype=tc, device=DEV)
+    ops.gemm(dA, dB, C2, M, N, K, A.shape[1], B.shape[1], N, ta, tb, bias=dev(bias), relu=True, accumulate=True)
+    assert relerr(host(C2), np.maximum(ref + bias, 0) + 0.5) < tol
+    if cdt == 'bf16':
+        gate = bf16_round(rng.standard_normal((M, N)))
+        C3 = torch.empty((M, N), dtype=tc, device=DEV)
+        ops.gemm(dA, dB, C3, M, N, K, A.shape[1], B.shape[1], N, ta, tb, relu_src=dev(gate, torch.bfloat16))
+        assert relerr(host(C3), ref * (gate > 0)) < tol
+    # exact comparison with the 128-tile kernels
+    Ai = rng.integers(-3, 4, size=A.shape).astype(np.float32)
+    Bi = rng.integers(-2, 3, size=B.shape).astype(np.float32)
+    outs = []
+    for use in (1, 0):
+        assert Clib.neurst_set_option(b'gemm256', use) == 0
+        Ci = torch.empty((M, N), dtype=tc, device=DEV)
+        ops.gemm(dev(Ai, torch.bfloat16), dev(Bi, torch.bfloat16), Ci, M, N, K, A.shape[1], B.shape[1], N, ta, tb)
+        outs.append(host(Ci))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], bf16_round((Ai.T if ta else Ai) @ (Bi.T if tb else Bi)) if cdt == 'bf16' else (Ai.T if ta else Ai) @ (Bi.T if tb else Bi))
+
+
+def test_gemm_256_tile_kernel_is_chosen_for_long_reductions_only():
+    """the production rule (measured): K >= 2560 with K-contiguous operands, K >= 8192, or a wide fp32 result"""
+    rng = np.random.default_rng(3)
+    M, N, K = 16000, 768, 3072
+    A = bf16_round(rng.standard_normal((M, K)) * 0.1)
+    B = bf16_round(rng.standard_normal((N, K)) * 0.1)
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(dev(A, torch.bfloat16), dev(B, torch.bfloat16), C, M, N, K, K, K, N, 0, 1)
+    got = host(C)[::97]
+    assert relerr(got, A[::97].astype(np.float64) @ B.T.astype(np.float64)) < 1e-2
+
+
+@pytest.mark.parametrize('shapes', [[(2304, 768), (768, 768), (3072, 768), (768, 3072)], [(776, 520), (264, 200)], [(480, 768)] * 8])
+def test_grouped_weight_gradients(shapes):
+    """neurst_gemm_wgrad_bias_grouped: several layers' dW += dY^T . X and db += column sums of dY in one launch of whole-K
+    256 x 192 tiles, against numpy (fp64) and against one neurst_gemm_wgrad_bias launch per layer; a problem without a bias."""
+    rng = np.random.default_rng(len(shapes))
+    K = 1000 if shapes[0][0] < 1000 else 4096
+    probs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        A = bf16_round(rng.standard_normal((K, M)) * 0.1)
+        B = bf16_round(rng.standard_normal((K, N)) * 0.1)
+        C = torch.ones((M, N), dtype=torch.float32, device=DEV)
+        s = torch.full((M,), 2.0, dtype=torch.float32, device=DEV) if i != 1 else None
+        probs.append((dev(A, torch.bfloat16), dev(B, torch.bfloat16), C, s))
+        refs.append((A.T.astype(np.float64) @ B + 1.0, A.astype(np.float64).sum(0) + 2.0))
+    for rep in range(2):
+        ops.gemm_wgrad_grouped(probs)
+        for (a, b, C, s), (rc, rs) in zip(probs, refs):
+            assert relerr(host(C), rc + rep * (rc - 1.0)) < 1e-5
+            if s is not None:
+                assert relerr(host(s), rs + rep * (rs - 2.0)) < 1e-5
+    # same numbers as the per-layer entry point up to summation order
+    a, b, C, s = probs[0]
+    C1 = torch.ones_like(C)
+    s1 = torch.full_like(s, 2.0)
+    ops.gemm_wgrad_bias(a, b, C1, s1, 1, C.shape[0], C.shape[1], K, C.shape[0], C.shape[1], C.shape[1], split_k=2)
+    assert relerr(host(C1), refs[0][0]) < 1e-5 and relerr(host(s1), refs[0][1]) < 1e-5
+
+
+def test_set_option_rejects_unknown_names():
+    from neurst_amd import lib
+    C = lib.load()
+    assert C.neurst_set_option(b'no_such_switch', 1) == -1 and b'unknown option' in C.neurst_last_error()
+
+
 def test_colsum():
     rng = np.random.default_rng(1)
     x = rng.standard_normal((1000, 70)).astype(np.float32)

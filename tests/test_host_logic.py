@@ -220,6 +220,35 @@ def test_checkpoint_roundtrip_rename_and_average(tmp_path, fmt):
     assert all(np.allclose(v, 2.0 * b.export()[k]) for k, v in d.export().items())
 
 
+@pytest.mark.parametrize('t_steps,b1,b2,want', [(8, None, None, 8), (1200, 0.0, None, 1200), (1200, 0.0, 'exact', 1200), (50000, 0.0, 0.0, 50000),
+                                               (300, 'exact', None, 300)])
+def test_restore_of_a_tensorflow_written_checkpoint_recovers_adam_step(tmp_path, t_steps, b1, b2, want):
+    """A TF checkpoint has no adam_t, only beta1_power = 0.9^(t+1) and beta2_power = 0.98^(t+1) in fp32; beta1_power is
+    exactly 0.0 after ~1000 steps (log(0) used to raise OverflowError in restore), beta2_power after ~5000."""
+    import torch
+    from neurst_amd import ops
+    from neurst_amd.st.models.graph import VariableStore
+    from neurst_amd.st.tools.tftools import checkpointTools as ck
+    from neurst_amd.st.tools.tftools import tensorBundle as TB
+    specs = [('transformer/encoder/encoder_fc/kernel', (6, 4), 'glorot')]
+    a = VariableStore(specs, torch.device('cpu'), ops.F32, seed=3)
+    t = {}
+    for k, v in a.export().items():
+        t[k] = v
+        t[k + '/Adam'] = np.full_like(v, 0.25)
+        t[k + '/Adam_1'] = np.full_like(v, 0.5)
+    t['global_step'] = np.int64(t_steps)
+    t['beta1_power'] = np.float32(0.9) ** np.float32(t_steps + 1) if b1 in (None, 'exact') else np.float32(b1)
+    if b2 is not None:
+        t['beta2_power'] = np.float32(0.98) ** np.float32(t_steps + 1) if b2 == 'exact' else np.float32(b2)
+    prefix = str(tmp_path / ('model-%d' % t_steps))
+    TB.write_bundle(prefix, t)
+    b = VariableStore(specs, torch.device('cpu'), ops.F32, seed=9)
+    assert ck.restore(prefix, b) == t_steps
+    assert b.adam_t == want, b.adam_t
+    assert np.array_equal(b.export(b.m)['transformer/encoder/encoder_fc/kernel'], t['transformer/encoder/encoder_fc/kernel/Adam'])
+
+
 def test_tensor_bundle_container(tmp_path):
     """tensorBundle.py: the LevelDB-format index (prefix-compressed keys, several blocks, footer magic), block and
     tensor checksums, a snappy-compressed block, dtype / shape coverage and a TensorFlow-written state file."""
@@ -318,3 +347,70 @@ def test_run_lut_helpers(tmp_path):
     shards = [list(run_lut._Shard(stream, r, 4)) for r in range(4)]
     assert shards[0] == [0, 4, 8, 12, 16] and shards[3] == [3, 7, 11, 15, 19]     # whole rounds only: every rank takes the same number of steps
     assert sorted(sum(shards, [])) == list(range(20))
+
+
+EARLY_STOP_WORKER = r"""
+import os, sys, faulthandler
+faulthandler.dump_traceback_later(90, exit=True)
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+rank = int(sys.argv[1])
+os.environ.update(RANK=str(rank), WORLD_SIZE='2')
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2], rank=rank, world_size=2)
+from neurst_amd.st.bin import run_lut
+from neurst_amd.st.layers.arguments import AttrDict
+
+class Step:
+    value = 0
+class FakeModel:
+    # the gradient collective of the real step: a rank that keeps training after the others stopped blocks in here
+    def __init__(self):
+        self.global_step, self.last, self.store = Step(), {'lr': 1e-3}, None
+    def train_step(self, batch):
+        t = torch.ones(4)
+        dist.all_reduce(t)
+        assert float(t[0]) == 2.0
+        self.global_step.value += 1
+        return 1.0 / self.global_step.value, (2, 10, 4), 0.1, 0.2, 0.3
+class Reader:
+    def __init__(self, *a, **k): pass
+    def __iter__(self): return iter(range(10 ** 9))
+class Pre:
+    def __init__(self, it, depth=4): self.it = iter(it)
+    def __next__(self): return next(self.it)
+    def __iter__(self): return self
+    def close(self): pass
+class Summ:
+    def __init__(self, *a): pass
+    def summary_scalar(self, *a): pass
+dev_calls = []
+def fake_dev_test(args, step, *a, **k):
+    assert rank == 0, 'only rank 0 scores the dev set'
+    dev_calls.append(step)
+    return 0.5, 0.5 + 0.01 * len(dev_calls), 10.0 - len(dev_calls)     # never better than the first: bad_count grows
+run_lut.build_models = lambda args: (FakeModel(), FakeModel())
+run_lut.TFReader, run_lut.Prefetcher, run_lut.Summary, run_lut.dev_test = Reader, Pre, Summ, fake_dev_test
+run_lut.checkpointTools.save_checkpoint = lambda path, *a, **k: path
+args = AttrDict({'dir_checkpoint': sys.argv[3], 'dir_log': sys.argv[3], 'dirs': {'train': {'tfdata': 'x'}, 'dev': {'tfdata': 'y'}},
+                 'metrics': 'BLEU', 'early_stop': 2, 'dev_step': 3, 'num_epochs': 1000, 'data': {'unit': 'word'}, 'dim_output': 11, 'eos_idx': 3})
+losses = run_lut.train(args)
+# dev passes at step 0, 3, 6, 9, ...: the first saves, the next three are worse -> bad_count 3 > early_stop 2 at step 9
+assert len(losses) == 10, len(losses)
+if rank == 0:
+    assert dev_calls == [0, 3, 6, 9], dev_calls
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'stopped after', len(losses), 'steps')
+"""
+
+
+def test_early_stop_reaches_every_rank(tmp_path):
+    """st/bin/run_lut.py:420-422 with one process per GPU: rank 0 alone scores the dev set, but its early-stop decision
+    must end the loop on EVERY rank - a rank that trained on would block in the next gradient all-reduce for good."""
+    script = tmp_path / 'worker.py'
+    script.write_text(EARLY_STOP_WORKER % ROOT)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=150)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all('stopped after 10 steps' in o for o in outs), outs

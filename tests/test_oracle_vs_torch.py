@@ -7,7 +7,7 @@ import torch
 from oracle import ops
 from oracle.model import OracleTPE, TPEConfig, init_params
 from neurst_amd.synthetic import make_batch
-import torch_ref
+from oracle import torch_graph as torch_ref
 
 
 def tiny_cfg(**kw):

@@ -18,6 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def gemm_label(name):
     """mangled / half-demangled gemm_kernel<T, TC, TA, TB_KCONTIG, FAST, SUMOP, NS> -> the label bench.py uses"""
+    if 'gemm256_group_kernel' in name:
+        return 'gemm256_group_kernel'
+    m2 = re.match(r'_ZN2t214gemm256_kernelI(DF16b|f)Lb([01])ELb([01])E', name)
+    if m2:
+        lay = {('0', '1'): 'NT', ('0', '0'): 'NN', ('1', '0'): 'TN', ('1', '1'): 'TT'}[m2.groups()[1:]]
+        return 'gemm256_kernel<bf16,%s,%s>' % ('bf16' if m2.group(1) == 'DF16b' else 'f32', lay)
+    m2 = re.match(r'void t2::gemm256_kernel<(float|bool _Accum|__bf16), (true|false), (true|false)', name)
+    if m2:
+        lay = {('false', 'true'): 'NT', ('false', 'false'): 'NN', ('true', 'false'): 'TN', ('true', 'true'): 'TT'}[m2.groups()[1:]]
+        return 'gemm256_kernel<bf16,%s,%s>' % ('f32' if m2.group(1) == 'float' else 'bf16', lay)
     mp = re.match(r'_Z19gemm_persist_kernelI(DF16b|f)Lb([01])ELb([01])EEv8GemmArgs', name)
     if mp:
         lay = {('0', '1'): 'NT', ('0', '0'): 'NN', ('1', '0'): 'TN'}[mp.groups()[1:]]
@@ -53,18 +63,27 @@ def main(tag):
     src = os.path.join(ROOT, 'gpurun_out', tag)
     dst = os.path.join(ROOT, 'profiles')
     os.makedirs(dst, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_digest
     shutil.copy(os.path.join(src, 'stats', 's_kernel_stats.csv'), os.path.join(dst, tag + '_bench_lut_kernel_stats.csv'))
     f = counters(os.path.join(src, 'fetch', 'f_counter_collection.csv'))
     w = counters(os.path.join(src, 'write', 'w_counter_collection.csv'))
     out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams',
            'formula': 'bytes = 1000 * (2 * mean(FETCH_SIZE) + mean(WRITE_SIZE)); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 tallies 128-B reads at 64 B); Infinity-Cache hits are included',
+           'kernel_sources_digest': kernel_sources_digest(),
            'bytes_per_launch': {}, 'raw_kernel_names': {}}
     for k in sorted(f):
         fb = sum(f[k]) / len(f[k])
         wb = sum(w[k]) / len(w[k]) if k in w else 0.0
         label = gemm_label(k) or k.split('(')[0]
-        out['bytes_per_launch'][label] = round(1000 * (2 * fb + wb))
-        out['raw_kernel_names'][label] = {'name': k, 'launches': len(f[k]), 'fetch_kb': round(fb, 1), 'write_kb': round(wb, 1)}
+        # several instantiations can share a label (tile widths of gemm256): keep the launch-weighted mean
+        prev = out['raw_kernel_names'].get(label)
+        val = 1000 * (2 * fb + wb)
+        if prev:
+            n0, n1 = prev['launches'], len(f[k])
+            val = (out['bytes_per_launch'][label] * n0 + val * n1) / (n0 + n1)
+        out['bytes_per_launch'][label] = round(val)
+        out['raw_kernel_names'][label] = {'name': k, 'launches': len(f[k]) + (prev['launches'] if prev else 0), 'fetch_kb': round(fb, 1), 'write_kb': round(wb, 1)}
     json.dump(out, open(os.path.join(dst, tag + '_hbm_traffic.json'), 'w'), indent=1)
     mf = os.path.join(src, 'mfma', 'm_counter_collection.csv')
     if os.path.exists(mf):            # a fourth pass: --pmc MfmaUtil
