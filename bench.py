@@ -29,14 +29,17 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def lut_step_flops(B, T, L, Lb, V, d=768, din=480, nenc=4, nenc2=4, ndec=4):
-    """ALGORITHMIC forward FLOPs of one LUT step (SURVEY.md 8d formulas, 1 MAC = 2 flops); x3 for fwd+bwd."""
+def lut_step_flops(B, T, L, Lb, V, d=768, din=480, nenc=4, nenc2=4, ndec=4, T2=None, kd=True):
+    """ALGORITHMIC forward FLOPs of one train step (SURVEY.md 8d formulas, 1 MAC = 2 flops); x3 for fwd+bwd.  T2 = frames the
+    semantic encoder / decoder memory see (COSTT: the padded length after the shrink layer; LUT: T); kd: LUT's KD attention."""
     F = 4 * d
+    T2 = T if T2 is None else T2
     enc_blk = lambda rows, Tk: rows * (2 * d * 3 * d + 2 * d * d + 2 * 2 * d * F + 4 * Tk * d)
-    fwd = B * T * 2 * din * d + nenc * enc_blk(B * T, T) + B * T * 2 * d * V + nenc2 * enc_blk(B * T, T)
-    fwd += ndec * B * T * 4 * d * d                                     # decoder memory K/V projections
-    fwd += ndec * B * L * (8 * d * d + 4 * d * d + 16 * d * d + 4 * L * d + 4 * T * d) + B * L * 2 * d * V
-    fwd += B * T * 4 * d * d + B * Lb * (4 * d * d + 4 * T * d)         # KD attention
+    fwd = B * T * 2 * din * d + nenc * enc_blk(B * T, T) + B * T * 2 * d * V + nenc2 * enc_blk(B * T2, T2)
+    fwd += ndec * B * T2 * 4 * d * d                                    # decoder memory K/V projections
+    fwd += ndec * B * L * (8 * d * d + 4 * d * d + 16 * d * d + 4 * L * d + 4 * T2 * d) + B * L * 2 * d * V
+    if kd:
+        fwd += B * T2 * 4 * d * d + B * Lb * (4 * d * d + 4 * T2 * d)   # KD attention
     return fwd, 3 * fwd
 
 
@@ -297,8 +300,9 @@ def main():
 
     if rank == 0:
         d = args.model.encoder.num_cell_units
+        T2 = int(model.last['encoded'].shape[1]) if not is_lut else T      # COSTT: padded length after the shrink layer (data dependent)
         fwd, tot = lut_step_flops(B, T, Ln, 40, V, d=d, nenc=args.model.encoder.num_blocks, nenc2=args.model.encoder2.num_blocks,
-                                  ndec=args.model.decoder.num_blocks)
+                                  ndec=args.model.decoder.num_blocks, T2=T2, kd=is_lut)
         peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
         kern = timer.summary()
         roof = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'traffic': None,
@@ -321,7 +325,8 @@ def main():
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'LUT train step (configs/lut.yaml = configs_template/lut.yaml dims), %d x %d raw 80-dim fbank frames per GPU '
                                    '(T=%d), V=10000, L=U=Lb=%d, dropout 0.1, a1 splice on device' % (B, Traw, T, Ln) if is_lut else
-                                   'COSTT train step (configs/costt.yaml), %d x %d raw frames per GPU' % (B, Traw),
+                                   'COSTT train step (configs/costt.yaml = configs_template/costt.yaml dims: shrink layer, SpecAugment), %d x %d raw frames '
+                                   'per GPU (T=%d, %d after the shrink layer), V=10000, L=%d, dropout 0.1' % (B, Traw, T, T2, Ln),
                        'global_batch': B * world, 'frames_per_step': frames, 'raw_frames_per_s': 3 * frames / step_s,
                        'parallelism': 'dp%d' % world, 'loss': float(losses[0])},
             'roofline': roof,

@@ -158,6 +158,91 @@ def test_mean_of_tower_gradients_equals_full_batch_gradient():
     assert rel < 2e-2 and cos > 0.9995, (rel, cos)
 
 
+def _costt_model(num_blocks=None, dropout=None, dtype='bf16', V_=V, specaug=True):
+    """configs/costt.yaml (= configs_template/costt.yaml dims): d = 512, 8 heads of 64, 6 + 6 + 6 blocks, shrink layer, SpecAugment"""
+    from neurst_amd.st.layers.arguments import build_args, load_config
+    from neurst_amd.st.models.TransformerTPE import GlobalStep
+    cfg = load_config(os.path.join(ge.ROOT, 'configs', 'costt.yaml'))
+    for part in ('encoder', 'encoder2', 'decoder'):
+        if num_blocks:
+            cfg['model'][part]['num_blocks'] = num_blocks
+        if dropout is not None:
+            cfg['model'][part]['attention_dropout_rate'] = dropout
+            cfg['model'][part]['residual_dropout_rate'] = dropout
+    cfg['model']['use_specAug'] = specaug
+    cfg['beam_size'] = 1
+    args = build_args(cfg, dim_output=V_, compute_dtype=dtype)
+    assert args.model.shrink_layer and args.model.loss_type == 'ce_ctc' and args.model.encoder.num_cell_units == 512
+    return args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args), args
+
+
+def test_config3_costt_step_is_deterministic_at_full_width():
+    """BASELINE config 3 as `bench.py --config configs/costt.yaml` runs it (B = 32 x 1500 raw frames, L = 80, dropout 0.1,
+    SpecAugment, shrink layer): the same step twice gives bit-identical losses and gradients equal up to fp32 atomic order;
+    every value finite; the shrunk length stays within the frame count."""
+    model, _ = _costt_model()
+    batch = make_batch(B=B, Traw=1500, V=V, L=80, U=40, seed=12, ragged=True)
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in batch.items()}
+    a = model.forward_backward(batch).clone()
+    ga = model.store.grads.clone()
+    len_a = model.last['len_encoded'].clone()
+    b = model.forward_backward(batch).clone()
+    gb = model.store.grads
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.isfinite(ga).all()
+    den = ga.norm().item()
+    assert den > 0 and (ga - gb).norm().item() < 1e-4 * den
+    assert torch.equal(len_a, model.last['len_encoded']) and int(len_a.max()) <= 500 and int(len_a.min()) >= 0
+
+
+def test_config3_costt_mean_of_tower_gradients_equals_full_batch_gradient():
+    """the reference's data-parallel rule (gradientTools.py:7-37) on the COSTT graph at its template width (2 blocks each,
+    dropout and SpecAugment off, fp32 mode so that the arg-max decisions of the shrink layer are the same in both runs): the
+    shrunk tensors of the half batches are padded to their own maxima, the gradient must not see the difference."""
+    model, _ = _costt_model(num_blocks=2, dropout=0.0, dtype='fp32', V_=1000, specaug=False)
+    Bt = 8
+    host = make_batch(B=Bt, Traw=600, V=1000, L=30, U=16, seed=5, ragged=True)
+    dev = {k: torch.from_numpy(v).to(DEV) for k, v in host.items()}
+    full_loss = model.forward_backward(dev).clone()
+    full = model.store.grads.clone()
+    acc = torch.zeros_like(full)
+    losses = []
+    for h in range(2):
+        half = {k: v[h * Bt // 2:(h + 1) * Bt // 2].contiguous() for k, v in dev.items()}
+        losses.append(model.forward_backward(half).clone())
+        acc += model.store.grads
+    acc *= 0.5
+    assert torch.allclose((losses[0] + losses[1]) * 0.5, full_loss, rtol=1e-5, atol=1e-6), (losses, full_loss)
+    rel = (acc - full).norm().item() / full.norm().item()
+    assert rel < 1e-4, rel
+
+
+def test_shrink_gather_scatter_round_trip_at_config3_size():
+    """blocks.py:8-38 at T = 500, d = 512, B = 32: scatter(gather(x)) returns x on the kept frames and zero elsewhere,
+    gather(scatter(y)) returns y on the first new_len rows; kept frames are exactly the non-blank, non-repeated arg-maxes."""
+    rng = np.random.default_rng(3)
+    Bq, T, D = 32, 500, 512
+    blank = 99
+    am = rng.integers(90, 100, size=(Bq, T)).astype(np.int32)            # many blanks and repeats
+    lens = rng.integers(250, T + 1, size=Bq).astype(np.int32)
+    lens[0] = T
+    am[1, :] = blank                                                       # an utterance that keeps nothing
+    x = torch.from_numpy(rng.standard_normal((Bq, T, D)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    index, new_len = ops.shrink_index(torch.from_numpy(am).to(DEV), torch.from_numpy(lens).to(DEV), blank)
+    prev = np.concatenate([np.full((Bq, 1), blank, np.int32), am[:, :-1]], 1)
+    keep = (am != blank) & (am != prev) & (np.arange(T)[None] < lens[:, None])
+    assert np.array_equal(new_len.cpu().numpy(), keep.sum(1)) and int(new_len[1]) == 0
+    Tout = max(int(new_len.max()), 1)
+    y = ops.shrink_fwd(x, index, Tout)
+    back = ops.shrink_bwd(y, index, T)
+    kd = torch.from_numpy(keep).to(DEV)
+    assert torch.equal(back[kd], x[kd]) and float(back[~kd].float().abs().max()) == 0.0
+    y2 = ops.shrink_fwd(back, index, Tout)
+    assert torch.equal(y2, y)
+    valid = torch.arange(Tout, device=DEV)[None] < new_len[:, None]
+    assert float(y[~valid].float().abs().max()) == 0.0
+
+
 def test_beam_kernels_at_full_vocabulary_and_batch():
     """beam search bookkeeping at LUT scale (32 utterances x 4 hypotheses, V = 10000): top-k agrees with torch.topk of
     the log-softmax, a pruning step keeps the best candidates in order, and parents / gathers stay inside the utterance"""

@@ -478,7 +478,8 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
     base = [os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
     runs = [[sys.executable] + base,
             [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-             '--master-port', '29713'] + base]
+             '--master-port', '29713'] + base,
+            [sys.executable] + base + ['--config', os.path.join(root, 'configs', 'costt.yaml')]]      # BASELINE config 3
     for cmd in runs:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -495,3 +496,5 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
             assert k in r, k
         assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
         assert abs(d['value'] - 32 * 500 / (d['ms_per_step'] / 1e3)) < 1e-3 * d['value']
+        assert ('COSTT' in d['config']['workload']) == ('costt.yaml' in cmd[-1])
+        assert 0 < r['step_frac'] < 1 and 'traffic_stale' in r
