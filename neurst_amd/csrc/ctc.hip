@@ -14,7 +14,7 @@ struct CtcWs {
   int32_t* next;    // [B][Smax]  next state with the same symbol, -1 = none
   int32_t* first;   // [B][Smax]  1 if no earlier state has the same symbol
   int32_t* meta;    // [B][4]     S, active(1: run recursion), nopath, unused
-  double* logy;     // [B][T][Smax]  fp64: the recursion adds T of these, fp32 log-space would cost ~1e-5 in the posteriors
+  double* logy;     // [B][T][Smax]  fp64 emission probabilities y_t(l'_u) = softmax(logits_t)[l'_u] (name kept from the log-space form)
   double* alpha;    // [B][T][Smax]  overwritten by the posteriors
 };
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) ctc_frame_kernel(const float* __restrict_
     const int32_t* lp = w.lp + b * Smax;
     double* ly = w.logy + bt * Smax;
     const double lse = (double)st.m + log((double)st.s);
-    for (int u = threadIdx.x; u < S; u += blockDim.x) ly[u] = (double)src[lp[u]] - lse;
+    for (int u = threadIdx.x; u < S; u += blockDim.x) ly[u] = exp((double)src[lp[u]] - lse);
   }
   // in-place safe: every element is read (from the LDS cache or by the same thread) before it is written
   for (int i = threadIdx.x; i < V; i += blockDim.x) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) ctc_frame_reg_kernel(const float* __restr
     double* ly = w.logy + bt * Smax;
     const double lse = (double)st.m + log((double)sum);
     const float* row = logits + bt * V;
-    for (int u = tid; u < S; u += 256) ly[u] = (double)row[lp[u]] - lse;
+    for (int u = tid; u < S; u += 256) ly[u] = exp((double)row[lp[u]] - lse);
   }
   __syncthreads();   // in-place gradient: the label columns above are read before any element is overwritten
   const float k = active ? grad_scale / sum : 0.f;
@@ -218,75 +218,204 @@ __global__ void __launch_bounds__(256) ctc_frame_reg_kernel(const float* __restr
   }
 }
 
-__device__ __forceinline__ double lse3(double a, double b, double c) {
-  double m = fmax(a, fmax(b, c));
-  if (m == -INFINITY) return -INFINITY;
-  return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+// ---- B: alpha / beta recursion, ONE wavefront per utterance.
+// Lane l owns the NPL consecutive states l*NPL .. l*NPL+NPL-1 of l' (S = 2U+1 <= 64 NPL), so a frame's update needs two values of
+// the previous (alpha) or next (beta) lane, moved with DPP wave shifts: no LDS, no barrier.  A log-space recursion (round 1:
+// one thread per state, fp64, 986 us at T = 500) spends its time in three exp and one log per state and frame; here the
+// arithmetic is LINEAR fp64 with rescaling - alpha_t(u) =
+// y_t(u) (alpha(u) + alpha(u-1) + [skip] alpha(u-2)) on probabilities y (written by the frame kernel), every 4th frame divided
+// by the power of two below the wave's sum (exact; the exponents add up to log2 of the scale of p).  All terms are positive, so there is no cancellation: the
+// result agrees with the log-space recursion to ~1e-13.  The posteriors need no scale at all: alpha_t(u) beta_t(u) summed
+// over u is p(l|x) times the frame's scale for EVERY t (beta excludes the emission at t), so post_t(u) = alpha beta / sum_u alpha beta.
+__device__ __forceinline__ double dpp_f64(double x, double fill, const int ctrl_is_shl) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+  if (ctrl_is_shl) {   // value of lane l + 1 (lane 63 keeps `fill`)
+    lo = __builtin_amdgcn_update_dpp(flo, lo, 0x130, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x130, 0xF, 0xF, false);
+  } else {             // value of lane l - 1 (lane 0 keeps `fill`)
+    lo = __builtin_amdgcn_update_dpp(flo, lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x138, 0xF, 0xF, false);
+  }
+  return __hiloint2double(hi, lo);
+}
+// wave-wide fp64 sum over the DPP network (the six steps of wave_sum_dpp in common.h on both halves of the double): a few
+// cycles per step, against ~100 of latency for each of the twelve LDS-crossbar shuffles of a __shfl_xor butterfly
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_step_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_step_f64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_step_f64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_step_f64<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_step_f64<0x140, 0xF>(v);   // row_mirror
+  v += dpp_step_f64<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_step_f64<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
-// ---- B: alpha / beta recursion (fp64 log space), one workgroup per utterance, one thread per state
-__global__ void ctc_alpha_beta_kernel(const int32_t* __restrict__ len_logits, CtcWs w, float* __restrict__ loss, int64_t T, int64_t Smax) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* buf = reinterpret_cast<double*>(smem);   // [2][Smax + 4], two leading / trailing -inf guards
+template <int NPL>
+__global__ void __launch_bounds__(64) ctc_alpha_beta_wave_kernel(const int32_t* __restrict__ len_logits, CtcWs w, float* __restrict__ loss, int64_t T,
+                                                                  int64_t Smax) {
   const int64_t b = blockIdx.x;
-  const int u = threadIdx.x;
+  const int lane = threadIdx.x;
   const int S = w.meta[b * 4 + 0];
   int Tb = len_logits[b];
   Tb = Tb > T ? (int)T : Tb;
-  if (!w.meta[b * 4 + 1]) { if (u == 0) loss[b] = 0.f; return; }
+  if (!w.meta[b * 4 + 1]) { if (lane == 0) loss[b] = 0.f; return; }
   const int32_t* lp = w.lp + b * Smax;
-  const double* logy = w.logy + b * T * Smax;
+  const double* yv = w.logy + b * T * Smax;         // probabilities y_t(u) (linear), written by the frame kernel
   double* alpha = w.alpha + b * T * Smax;
-  const int stride = (int)Smax + 4;
-  double* b0 = buf + 2;
-  double* b1 = buf + stride + 2;
-  const double NINF = -INFINITY;
-  for (int i = u; i < 2 * stride; i += blockDim.x) buf[i] = NINF;
-  __syncthreads();
-  const bool live = u < S;
+  const int u0 = lane * NPL;
   const int blank = lp[0];
-  const bool skip_in = live && u >= 2 && lp[u] != blank && lp[u] != lp[u - 2];        // u-2 -> u allowed
-  const bool skip_out = live && u + 2 < S && lp[u + 2] != blank && lp[u + 2] != lp[u];  // u -> u+2 allowed
-  double a = (live && u < 2) ? logy[u] : NINF;
-  if (live) { alpha[u] = a; b0[u] = a; }
-  __syncthreads();
-  double* cur = b0;
-  double* nxt = b1;
-  for (int t = 1; t < Tb; ++t) {
-    if (live) {
-      a = lse3(cur[u], cur[u - 1], skip_in ? cur[u - 2] : NINF) + logy[(int64_t)t * Smax + u];
-      alpha[(int64_t)t * Smax + u] = a;
-      nxt[u] = a;
+  bool skip_in[NPL], skip_out[NPL], live[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int u = u0 + i;
+    live[i] = u < S;
+    skip_in[i] = live[i] && u >= 2 && lp[u] != blank && lp[u] != lp[u - 2];
+    skip_out[i] = live[i] && u + 2 < S && lp[u + 2] != blank && lp[u + 2] != lp[u];
+  }
+  auto load_row = [&](const double* row, double (&v)[NPL]) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = live[i] ? row[u0 + i] : 0.0;
+  };
+  // Frames are fetched BLK at a time, one block ahead of the recursion: a frame's update is ~100 cycles of dependent
+  // fp64 arithmetic, a global load ~1000 - fetched frame by frame (first version: 717 us at T = 500) the loop only waits.
+  constexpr int BLK = NPL <= 2 ? 8 : (NPL <= 4 ? 4 : (NPL <= 8 ? 2 : 1));
+  auto load_block = [&](const double* base, int t0, int step, double (&v)[BLK][NPL]) {   // frames t0, t0 + step, ... (inside [0, Tb))
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {
+      const int t = t0 + j * step;
+      const bool ok = t >= 0 && t < Tb;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) v[j][i] = (ok && live[i]) ? base[(int64_t)t * Smax + u0 + i] : 0.0;
     }
-    __syncthreads();
-    double* tmp = cur; cur = nxt; nxt = tmp;
-  }
-  const double logp = lse3(cur[S - 1], S >= 2 ? cur[S - 2] : NINF, NINF);
-  __syncthreads();
-  if (u == 0) {
-    loss[b] = (float)(-logp);
-    if (logp == NINF) w.meta[b * 4 + 2] = 1;   // no valid path: gradient stays softmax
-  }
-  if (logp == NINF) return;
-  // beta (emission at t excluded): beta[T-1][u] = 0 for the last two states
-  double be = (live && u >= S - 2) ? 0.0 : NINF;
-  if (live) {
-    int64_t o = (int64_t)(Tb - 1) * Smax + u;
-    double post = exp(alpha[o] + be - logp);
-    cur[u] = be + logy[o];
-    alpha[o] = post;
-  }
-  __syncthreads();
-  for (int t = Tb - 2; t >= 0; --t) {
-    if (live) {
-      be = lse3(cur[u], cur[u + 1], skip_out ? cur[u + 2] : NINF);
-      int64_t o = (int64_t)t * Smax + u;
-      double post = exp(alpha[o] + be - logp);
-      nxt[u] = be + logy[o];
-      alpha[o] = post;
+  };
+  // ---------------- alpha
+  double a[NPL], y[BLK][NPL], yn[BLK][NPL];
+  {
+    double y0[NPL];
+    load_row(yv, y0);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      a[i] = (live[i] && u0 + i < 2) ? y0[i] : 0.0;
+      if (live[i]) alpha[u0 + i] = a[i];
     }
-    __syncthreads();
-    double* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  int64_t scale_exp = 0;                 // log2 of the product of all divisors
+  load_block(yv, 1, 1, y);
+  for (int tb = 1; tb < Tb; tb += BLK) {
+    load_block(yv, tb + BLK, 1, yn);
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {
+      const int t = tb + j;
+      if (t < Tb) {
+        const double pm1 = dpp_f64(a[NPL - 1], 0.0, 0);                         // state u0 - 1
+        const double pm2 = dpp_f64(NPL >= 2 ? a[NPL - 2] : 0.0, 0.0, 0);        // state u0 - 2
+        double na[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const double m1 = i >= 1 ? a[i - 1] : pm1;
+          const double m2 = i >= 2 ? a[i - 2] : (i == 1 ? pm1 : pm2);
+          na[i] = y[j][i] * (a[i] + m1 + (skip_in[i] ? m2 : 0.0));
+        }
+        if ((t & 3) == 0) {                                                      // rescale: keeps the row near 1
+          double sum = 0.0;
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) sum += na[i];
+          sum = wave_sum_f64(sum);
+          if (sum > 0.0) {                                                       // by the power of two below the sum: exact, no
+            const int e = __builtin_amdgcn_frexp_exp(sum);                       // division or logarithm on the recurrence
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) na[i] = ldexp(na[i], -e);
+            scale_exp += e;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          a[i] = na[i];
+          if (live[i]) alpha[(int64_t)t * Smax + u0 + i] = a[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; ++j)
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) y[j][i] = yn[j][i];
+  }
+  // p(l | x) = alpha_{T-1}(S-1) + alpha_{T-1}(S-2)
+  double tail = 0.0;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+    if (live[i] && u0 + i >= S - 2) tail += a[i];
+  tail = wave_sum_f64(tail);
+  const bool nopath = !(tail > 0.0);
+  if (lane == 0) {
+    loss[b] = nopath ? INFINITY : (float)(-((double)scale_exp * 0.6931471805599453094 + log(tail)));
+    if (nopath) w.meta[b * 4 + 2] = 1;     // no valid path: gradient stays softmax
+  }
+  if (nopath) return;
+  // ---------------- beta (emission at t excluded) and posteriors, written over alpha
+  double be[NPL], at[BLK][NPL], atn[BLK][NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) be[i] = (live[i] && u0 + i >= S - 2) ? 1.0 : 0.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's own alpha stores, re-read below
+  load_block(yv, Tb - 1, -1, y);
+  load_block(alpha, Tb - 1, -1, at);
+  for (int tb = Tb - 1; tb >= 0; tb -= BLK) {
+    load_block(yv, tb - BLK, -1, yn);
+    load_block(alpha, tb - BLK, -1, atn);
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {
+      const int t = tb - j;
+      if (t >= 0) {
+        // posterior of frame t
+        double ab[NPL], sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) { ab[i] = at[j][i] * be[i]; sum += ab[i]; }
+        sum = wave_sum_f64(sum);
+        const double inv = sum > 0.0 ? 1.0 / sum : 0.0;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+          if (live[i]) alpha[(int64_t)t * Smax + u0 + i] = ab[i] * inv;
+        // beta_{t-1}(u) = z(u) + z(u+1) + [skip] z(u+2), z = beta_t y_t
+        double z[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) z[i] = be[i] * y[j][i];
+        const double np1 = dpp_f64(z[0], 0.0, 1);                                // state u0 + NPL
+        const double np2 = dpp_f64(NPL >= 2 ? z[1] : 0.0, 0.0, 1);               // state u0 + NPL + 1
+        double nb[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const double p1 = i + 1 < NPL ? z[i + 1] : np1;
+          const double p2 = i + 2 < NPL ? z[i + 2] : (i + 2 == NPL ? np1 : np2);
+          nb[i] = z[i] + p1 + (skip_out[i] ? p2 : 0.0);
+        }
+        if ((t & 3) == 0) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) s2 += nb[i];
+          s2 = wave_sum_f64(s2);
+          if (s2 > 0.0) {
+            const int e = __builtin_amdgcn_frexp_exp(s2);
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) nb[i] = ldexp(nb[i], -e);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) be[i] = nb[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BLK; ++j)
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) { y[j][i] = yn[j][i]; at[j][i] = atn[j][i]; }
   }
 }
 
@@ -347,8 +476,11 @@ extern "C" int neurst_ctc_loss_fwd_bwd_phased(const float* logits, const int32_t
   NEURST_CHECK_LAUNCH("ctc_frame");
   }
   if (!(phases & 2)) return NEURST_OK;
-  int nthr = (int)((Smax + 63) / 64 * 64);
-  ctc_alpha_beta_kernel<<<(int)B, nthr, 2 * (Smax + 4) * sizeof(double), s>>>(len_logits, w, loss, T, Smax);
+  const int npl = (int)((Smax + 63) / 64);
+  if (npl <= 2) ctc_alpha_beta_wave_kernel<2><<<(int)B, 64, 0, s>>>(len_logits, w, loss, T, Smax);
+  else if (npl <= 4) ctc_alpha_beta_wave_kernel<4><<<(int)B, 64, 0, s>>>(len_logits, w, loss, T, Smax);
+  else if (npl <= 8) ctc_alpha_beta_wave_kernel<8><<<(int)B, 64, 0, s>>>(len_logits, w, loss, T, Smax);
+  else ctc_alpha_beta_wave_kernel<16><<<(int)B, 64, 0, s>>>(len_logits, w, loss, T, Smax);
   NEURST_CHECK_LAUNCH("ctc_alpha_beta");
   if (grad_dtype == NEURST_BF16)
     ctc_grad_fix_kernel<bf16_t><<<(unsigned)(B * T), 128, 0, s>>>(len_logits, w, (bf16_t*)grad, T, (int)V, Smax, grad_scale);
