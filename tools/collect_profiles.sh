@@ -9,7 +9,8 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cmd="python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $cmd > $out/stats.log 2>&1 &&
+scmd="python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --serial-streams"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $scmd > $out/stats.log 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $cmd > $out/fetch.log 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $cmd > $out/write.log 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc MfmaUtil --output-format csv -d $out/mfma -o m -- $cmd > $out/mfma.log 2>&1
