@@ -116,9 +116,11 @@ int neurst_mha_bwd(const void* q, const void* k, const void* v, const void* o, c
                    int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
 
 /* Training variants of the two calls above that carry the attention-dropout decisions from forward to backward:
- * keep_bits (neurst_mha_keep_bits_bytes(B,H,Tq,Tk) bytes, may be NULL = hash again in backward) receives, per
- * 64x64 score tile, the 16-bit keep mask each forward thread computed; the backward kernels read it back instead of
- * re-hashing.  Same results bit for bit (st/layers/common_attention_v1.py:357-359: TF keeps the mask tensor). */
+ * keep_bits (neurst_mha_keep_bits_bytes(B,H,Tq,Tk) bytes, 4-byte aligned, may be NULL = hash again in backward) receives
+ * the keep decisions as a row-major bitmap, uint32 [B*H][Tq][ceil(Tk/32)]: bit (k & 31) of word (k >> 5) of row
+ * (b*H + h)*Tq + q is 1 when weight (q, k) is kept (words of tiles the forward skips as fully masked stay unwritten);
+ * the backward kernels read it back instead of re-hashing.  Same results bit for bit
+ * (st/layers/common_attention_v1.py:357-359: TF keeps the mask tensor). */
 int64_t neurst_mha_keep_bits_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk);
 int neurst_mha_fwd_train(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits,
                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,

@@ -173,10 +173,10 @@ struct AttnArgs {
   float keep_scale, qscale;
   int q_aligned, k_aligned, v_aligned, o_aligned;
   int out_vec, dq_vec, dk_vec, dv_vec;   // 4 consecutive head columns may be stored as one vector
-  // optional [B*H][ceil(Tq/64)][ceil(Tk/64)][256] u16: the 16 dropout keep decisions each forward thread made for one tile;
-  // written by the forward, read back by both backward kernels instead of re-hashing 16 indices per thread and tile
-  uint16_t* keep_bits;
-  int nqt, nkt;
+  // optional [B*H][Tq][ceil(Tk/32)] u32, row-major bitmap of the dropout keep decisions: bit (k & 31) of word k >> 5 of row
+  // (b*H + h)*Tq + q.  Written by the forward, read back by the backward kernels instead of re-hashing every index.
+  uint32_t* keep_bits;
+  int nw;                // words per bitmap row
   int keep_bits_ready;   // forward: keep_bits already holds the decisions (neurst_mha_keep_bits): load them instead of hashing
 };
 
@@ -212,6 +212,34 @@ __device__ __forceinline__ uint32_t keep_bits16(const AttnArgs& a, uint64_t base
   }
   asm volatile("" : "+v"(m));
   return m;
+}
+
+// The 16 decisions of keep_bits16(base, col0 = kv0 + 4g, 16, 1) (bit nt*4 + r <-> key kv0 + 16 nt + 4 g + r) <-> the two bitmap
+// words of the 64-key tile: word (nt >> 1), bits 16 (nt & 1) + 4 g + r.
+__device__ __forceinline__ void kmask_to_words(uint32_t kmask, int g, uint32_t& w0, uint32_t& w1) {
+  w0 = ((kmask & 0xFu) << (4 * g)) | (((kmask >> 4) & 0xFu) << (16 + 4 * g));
+  w1 = (((kmask >> 8) & 0xFu) << (4 * g)) | (((kmask >> 12) & 0xFu) << (16 + 4 * g));
+}
+__device__ __forceinline__ uint32_t words_to_kmask(uint32_t w0, uint32_t w1, int g) {
+  return ((w0 >> (4 * g)) & 0xFu) | (((w0 >> (16 + 4 * g)) & 0xFu) << 4) | (((w1 >> (4 * g)) & 0xFu) << 8) | (((w1 >> (16 + 4 * g)) & 0xFu) << 12);
+}
+// lanes l, l^16, l^32, l^48 hold the four nibble groups of one query's words: OR them and let the g == 0 lane store
+__device__ __forceinline__ void store_keep_words(const AttnArgs& a, uint32_t kmask, int lane, int64_t row, bool row_ok, int64_t kv0) {
+  uint32_t w0, w1;
+  kmask_to_words(kmask, lane >> 4, w0, w1);
+  w0 |= __shfl_xor(w0, 16, 64); w1 |= __shfl_xor(w1, 16, 64);
+  w0 |= __shfl_xor(w0, 32, 64); w1 |= __shfl_xor(w1, 32, 64);
+  if (lane < 16 && row_ok) {
+    uint32_t* p = a.keep_bits + row * a.nw + (kv0 >> 5);
+    p[0] = w0;
+    if ((kv0 >> 5) + 1 < a.nw) p[1] = w1;
+  }
+}
+__device__ __forceinline__ uint32_t load_keep_words(const AttnArgs& a, int lane, int64_t row, bool row_ok, int64_t kv0) {
+  if (!row_ok) return 0u;
+  const uint32_t* p = a.keep_bits + row * a.nw + (kv0 >> 5);
+  const uint32_t w0 = p[0], w1 = (kv0 >> 5) + 1 < a.nw ? p[1] : 0u;
+  return words_to_kmask(w0, w1, lane >> 4);
 }
 
 __device__ __forceinline__ float quad_groups_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
@@ -317,10 +345,10 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
     float lsum = 0.f;
     uint32_t kmask;
     if (a.keep_bits_ready) {
-      kmask = a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid];
+      kmask = load_keep_words(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0);
     } else {
       kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
-      if (a.keep_bits && a.thr) a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid] = (uint16_t)kmask;
+      if (a.keep_bits && a.thr) store_keep_words(a, kmask, lane, bh * a.Tq + qi, qi < a.Tq, kv0);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -418,7 +446,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArg
       vreg.load(vg, a.ldv, kv0 + 64, a.Tk, dh, a.v_aligned, tid);
     }
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q_tail;
-    const uint32_t kmask = (a.keep_bits && a.thr) ? (uint32_t)a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid]
+    const uint32_t kmask = (a.keep_bits && a.thr) ? load_keep_words(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0)
                                                   : keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
     f32x4 ds[4];
 #pragma unroll
@@ -471,7 +499,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
   T* dOs = Qs + 64 * LDK;                             // [64][LDK]
   float* lse_s = reinterpret_cast<float*>(dOs + 64 * LDK);  // [64]
   float* del_s = lse_s + 64;                          // [64]
-  uint16_t* mask_s = reinterpret_cast<uint16_t*>(del_s + 64);   // [4][64]: the forward threads' keep bits of this (q tile, kv tile)
+  uint32_t* mask_s = reinterpret_cast<uint32_t*>(del_s + 64);   // [2][64]: the two bitmap words of this 64-key tile for each of the 64 staged queries
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
   const BlockId bid = remap_block();
   const int64_t b = bid.z, h = bid.y, kv0 = bid.x * 64;
@@ -498,14 +526,16 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
 
   TileRegs<T, DH, FULL> qreg, doreg;
   float lse_reg = 0.f, del_reg = 0.f;   // threads 0..63: statistics of query q0 + tid of the staged tile
-  uint32_t mask_reg = 0;                // threads 64..191: two of the 256 stored keep masks of the tile
+  uint32_t mask_reg = 0;                // threads 64..191: bitmap word (tid - 64) >> 6 of query (tid - 64) & 63
   const bool stored = a.keep_bits && a.thr;
   auto load_stats = [&](int64_t q0n) {
     const int64_t qi = q0n + tid;
     if (tid < 64 && qi < a.Tq) { lse_reg = a.lse_in[bh * a.Tq + qi] * unit; del_reg = a.delta[bh * a.Tq + qi]; }
     else { lse_reg = 0.f; del_reg = 0.f; }
-    if (stored && tid >= 64 && tid < 192)
-      mask_reg = reinterpret_cast<const uint32_t*>(a.keep_bits + ((bh * a.nqt + (q0n >> 6)) * a.nkt + bid.x) * 256)[tid - 64];
+    if (stored && tid >= 64 && tid < 192) {
+      const int64_t qm = q0n + ((tid - 64) & 63), wi = (kv0 >> 5) + ((tid - 64) >> 6);
+      mask_reg = (qm < a.Tq && wi < a.nw) ? a.keep_bits[(bh * a.Tq + qm) * a.nw + wi] : 0u;
+    }
   };
   if (q_begin < a.Tq) {
     qreg.load(qg, a.ldq, q_begin, a.Tq, dh, a.q_aligned, tid);
@@ -524,7 +554,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
     qreg.store(Qs, tid);
     doreg.store(dOs, tid);
     if (tid < 64) { lse_s[tid] = lse_reg; del_s[tid] = del_reg; }
-    else if (stored && tid < 192) reinterpret_cast<uint32_t*>(mask_s)[tid - 64] = mask_reg;
+    else if (stored && tid < 192) mask_s[tid - 64] = mask_reg;
     __syncthreads();
 #if DKV_PREFETCH
     if (q0 + 64 < a.Tq) {
@@ -534,17 +564,17 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
     }
 #endif
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q0 + 64 > a.Tq;
-    // weight (q = q0 + 16 nt + g4 + r, key kj): hashed here, or bit (4 w + (lane & 3)) of the mask the forward thread
-    // (wave nt, lane (g4 + r) + 16 ((lane & 15) >> 2)) stored - four neighbouring u16, one 8-byte LDS read per nt
+    // weight (q = q0 + 16 nt + g4 + r, key kj): hashed here, or bit (kj & 31) of the query's bitmap word - the words of four
+    // neighbouring queries come with one 16-byte LDS read per nt
     uint32_t kmask;
     if (stored) {
       kmask = 0;
-      const int sh = 4 * w + (lane & 3);
+      const int sh = (int)(kj & 31);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const uint64_t m4 = *reinterpret_cast<const uint64_t*>(mask_s + nt * 64 + 16 * ((lane & 15) >> 2) + g4);
+        const u32x4 m4 = *reinterpret_cast<const u32x4*>(mask_s + (w >> 1) * 64 + nt * 16 + g4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kmask |= (uint32_t)((m4 >> (16 * r + sh)) & 1u) << (nt * 4 + r);
+        for (int r = 0; r < 4; ++r) kmask |= ((m4[r] >> sh) & 1u) << (nt * 4 + r);
       }
     } else {
       kmask = keep_bits16(a, (uint64_t)((bh * a.Tq + q0) * a.Tk) + (uint64_t)kj, g4 * (int)a.Tk, 16 * (int)a.Tk, (int)a.Tk);
@@ -612,7 +642,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
 // ================================================================== host side
 template <typename T, int DH> static size_t fwd_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
 template <typename T, int DH> static size_t dq_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
-template <typename T, int DH> static size_t dkv_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD) + 128 * sizeof(float) + 512; }
+template <typename T, int DH> static size_t dkv_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD) + 128 * sizeof(float) + 128 * sizeof(uint32_t); }
 
 template <typename K>
 static int launch_attn(K kernel, dim3 grid, size_t smem, const AttnArgs& a, hipStream_t s, const char* name) {
@@ -639,7 +669,7 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.dh = (int)dh; a.mask_mode = mask_mode; a.len_k = len_k;
   a.thr = rate > 0.f ? rate_threshold(rate) : 0u;
   a.key = key; a.keep_scale = keep_scale(rate);
-  a.nqt = (int)cdiv64(Tq, 64); a.nkt = (int)cdiv64(Tk, 64);
+  a.nw = (int)cdiv64(Tk, 32);
   a.inner0 = fmix32(key);   // == fmix32(hi ^ key) with hi == 0
   a.idx32 = (double)B * (double)H * (double)Tq * (double)Tk < 4294967296.0;
   a.qscale = 1.0f / sqrtf((float)dh);
@@ -674,7 +704,7 @@ __global__ void __launch_bounds__(256) mha_keep_bits_kernel(AttnArgs a) {
   const int64_t bh = bid.z * a.H + bid.y, qi = bid.x * 64 + w * 16 + (lane & 15);
   const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
   for (int64_t kv0 = 0; kv0 < a.Tk; kv0 += 64)
-    a.keep_bits[((bh * a.nqt + bid.x) * a.nkt + (kv0 >> 6)) * 256 + tid] = (uint16_t)keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+    store_keep_words(a, keep_bits16(a, rowb, (int)kv0 + g4, 16, 1), lane, bh * a.Tq + qi, qi < a.Tq, kv0);
 }
 
 extern "C" int neurst_mha_keep_bits(uint16_t* keep_bits, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float rate, uint32_t key, void* stream) {
@@ -682,7 +712,7 @@ extern "C" int neurst_mha_keep_bits(uint16_t* keep_bits, int64_t B, int64_t H, i
   NEURST_CHECK_ARG(rate > 0.f && rate < 1.f, "mha_keep_bits: dropout rate must be in (0, 1)");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
-  a.keep_bits = keep_bits;
+  a.keep_bits = reinterpret_cast<uint32_t*>(keep_bits);
   a.ldq = a.ldk = a.ldv = a.ldo = 1;
   int rc = fill_args(a, B, H, Tq, Tk, 1, NEURST_MASK_NONE, nullptr, rate, key, NEURST_BF16);
   if (rc) return rc;
@@ -693,7 +723,7 @@ extern "C" int neurst_mha_keep_bits(uint16_t* keep_bits, int64_t B, int64_t H, i
 }
 
 extern "C" int64_t neurst_mha_keep_bits_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk) {
-  return B * H * cdiv64(Tq, 64) * cdiv64(Tk, 64) * 256 * (int64_t)sizeof(uint16_t);
+  return B * H * Tq * cdiv64(Tk, 32) * (int64_t)sizeof(uint32_t);
 }
 
 static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, uint16_t* keep_bits, int keep_bits_ready, int64_t ldq, int64_t ldk,
@@ -704,7 +734,7 @@ static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, fl
   NEURST_CHECK_ARG(((uintptr_t)keep_bits & 3) == 0, "mha_fwd: keep_bits must be 4-byte aligned");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
-  a.keep_bits = keep_bits;
+  a.keep_bits = reinterpret_cast<uint32_t*>(keep_bits);
   a.keep_bits_ready = keep_bits_ready;
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.bsq = bsq; a.bsk = bsk; a.bsv = bsv; a.bso = bso;
@@ -768,7 +798,7 @@ extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v,
   NEURST_CHECK_ARG(((uintptr_t)keep_bits & 3) == 0, "mha_bwd: keep_bits must be 4-byte aligned");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
-  a.keep_bits = const_cast<uint16_t*>(keep_bits);
+  a.keep_bits = reinterpret_cast<uint32_t*>(const_cast<uint16_t*>(keep_bits));
   a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.lse_in = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   int rc = fill_args(a, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, dtype);
