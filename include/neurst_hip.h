@@ -141,6 +141,21 @@ int neurst_mha_bwd_train(const void* q, const void* k, const void* v, const void
                          int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
                          int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype, void* stream);
 
+/* neurst_mha_bwd_train with a caller-provided workspace (neurst_mha_bwd_workspace_bytes(B,H,Tq,Tk,dh) bytes, 16-byte
+ * aligned; 0 bytes are needed when Tk <= 256).  With it, encoder-size bf16 problems (dh = 96, no causal mask, 16-byte aligned
+ * rows, stored keep_bits when rate > 0) run ONE fused kernel - five MFMA products per tile instead of the seven of the
+ * dq + dkv kernel pair, dQ summed over key blocks inside one workgroup through the workspace (no atomics, deterministic).
+ * Every other problem, or a NULL / too small workspace, takes the two-kernel path: same results up to bf16 rounding.
+ * Same reference arithmetic as neurst_mha_bwd (common_attention_v1.py:180-204,325-365 differentiated). */
+int64_t neurst_mha_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh);
+int neurst_mha_bwd_train_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                            const float* lse, const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv,
+                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                            int64_t lddq, int64_t lddk, int64_t lddv,
+                            int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
+                            int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
 /* a7 (+a6): out = LN(x + dropout(y)) * (t < len[b]) ; st/models/tools/utils.py:324-337,
  * st/layers/common_layers_v1.py:342-347 (eps 1e-6 inside rsqrt, biased variance).
  * z = x + dropout(y) is written over y (in place) for backward; mean/rstd [rows] fp32.

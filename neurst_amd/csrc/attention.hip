@@ -9,7 +9,7 @@
 // product runs on 16x16 MFMA tiles (bf16: 16x16x32, fp32 parity mode: 16x16x4).  Scores are computed
 // transposed so that each lane owns one query (or key): probabilities and dS stay in registers and feed
 // the second product directly (no LDS round trip), row statistics need two shuffles per tile.
-#include "common.h"
+#include "attention2.h"
 
 #define NEG_BIAS (-1e9f)
 #ifndef DKV_PREFETCH
@@ -782,6 +782,11 @@ extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v,
                                     int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq,
                                     int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
                                     void* stream);
+extern "C" int neurst_mha_bwd_train_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                       const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv, int64_t ldq, int64_t ldk,
+                                       int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq,
+                                       int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
+                                       void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" int neurst_mha_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                               float* delta, void* dq, void* dk, void* dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                               int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh,
@@ -794,6 +799,14 @@ extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v,
                                     int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq,
                                     int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
                                     void* stream) {
+  return neurst_mha_bwd_train_ws(q, k, v, o, d_o, lse, keep_bits, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv, B, H, Tq, Tk, dh,
+                                 mask_mode, len_k, rate, key, dtype, nullptr, 0, stream);
+}
+extern "C" int neurst_mha_bwd_train_ws(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                       const uint16_t* keep_bits, float* delta, void* dq, void* dk, void* dv, int64_t ldq, int64_t ldk,
+                                       int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t B, int64_t H, int64_t Tq,
+                                       int64_t Tk, int64_t dh, int mask_mode, const int32_t* len_k, float rate, uint32_t key, int dtype,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
   NEURST_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "mha_bwd: null pointer");
   NEURST_CHECK_ARG(((uintptr_t)keep_bits & 3) == 0, "mha_bwd: keep_bits must be 4-byte aligned");
   AttnArgs a;
@@ -806,6 +819,12 @@ extern "C" int neurst_mha_bwd_train(const void* q, const void* k, const void* v,
   NEURST_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh && lddq >= H * dh && lddk >= H * dh && lddv >= H * dh,
                    "mha_bwd: row stride smaller than H*dh");
   hipStream_t s = as_stream(stream);
+  {
+    Mha2Problem p = {q, k, v, o, d_o, lse, a.keep_bits, delta, dq, dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv, B, H, Tq, Tk, dh,
+                     mask_mode, len_k, rate, dtype};
+    NEURST_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "mha_bwd: workspace must be 16-byte aligned");
+    if (neurst_mha2_bwd_eligible(p, workspace ? workspace_bytes : 0)) return neurst_mha2_bwd_launch(p, static_cast<float*>(workspace), s);
+  }
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)H, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)H, (unsigned)B);
   if (dtype == NEURST_BF16) DISPATCH_DH(bf16_t, mha_bwd_dq_kernel, dq_smem, gq, "mha_bwd_dq");

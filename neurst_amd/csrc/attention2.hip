@@ -1,0 +1,456 @@
+// Fused attention backward for the encoder-size shapes (bf16, dh = 96 or 64, no causal mask): ONE kernel computes dQ, dK and
+// dV with five MFMA products per (32-query slice, 256-key block) instead of the seven of the dq + dkv kernel pair of
+// attention.hip, which stay the path for fp32 parity mode, causal masks, other head sizes and unaligned tensors.
+// Reference arithmetic as there: st/models/tools/utils.py:545-553, st/layers/common_attention_v1.py:180-204,325-365.
+//
+// One workgroup = 4 waves (one per SIMD, the whole 512-register file) = one (batch, head).  It walks the keys in blocks of
+// 256; wave w owns keys 64 w .. 64 w + 63 of the block (two 32-key MFMA columns) and keeps dK^T, dV^T of those keys in
+// 192 accumulator registers while the workgroup sweeps the queries in slices of 32:
+//   S  = Q.K^T, dP = dO.V^T   v_mfma_f32_32x32x16_bf16, key on the lane: A = rows of the Q / dO slice image (LDS, b128),
+//                              B = K / V fragments held in registers for the whole block
+//   P = exp2(c S - lse2), dS = P (keep/(1-rate) dP - delta)   in registers; the accumulator tiles are already the B operands
+//                              of the next two products (k order permuted: query 16 t + 8 (j >> 2) + 4 g + (j & 3))
+//   dV^T += dO^T.P, dK^T += Q^T.dS   A = transposed reads (ds_read_b64_tr_b16) of the same slice images
+//   dQ  = dS.K                sums over the key = the lane index: dS crosses LDS once, as a [key][query] image read back
+//                              transposed; K is a [key][d] LDS image of the block, read transposed as well
+//                              (v_mfma_f32_16x16x32_bf16, wave w: query half w & 1, three (two) 16-wide d blocks)
+// dQ needs the sum over key blocks: the workgroup owns all of them, so it carries the fp32 partial sums through a scratch
+// tensor between its passes (same thread writes and reads an element; no atomics, deterministic); with Tk <= 256 there is
+// one pass and no scratch traffic.  dQ of slice i - 1 is computed in iteration i, beside the vector work of slice i, so the
+// loop needs ONE barrier per slice.  Q / dO slices and the K image arrive by LDS-DMA (buffer_load ... lds) with the
+// bank swizzle applied on the source side; rows beyond the tensor read as zeros through the descriptor's range.
+#include "attention2.h"
+
+#define NEG_BIAS (-1e9f)
+// stops the scheduler from hoisting every LDS read of a phase to its start (registers); MFMA latency is covered by the chains' own length
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+namespace a2 {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+struct Args {
+  const bf16_t *q, *k, *v, *o, *d_o;
+  bf16_t *dq, *dk, *dv;
+  const float* lse;
+  float* delta;
+  float* ws;                 // [B*H][Tq][DH] fp32 partial dQ (only touched when Tk needs more than one key block)
+  const uint32_t* keep;      // row-major keep bitmap (attention.hip), or null when rate == 0
+  const int32_t* len_k;
+  int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  int64_t bsq, bsk, bsv, bso;
+  int B, H, Tq, Tk, nw, keypad;
+  float qscale, keep_scale;
+};
+
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned records) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, records, 0x00020000u};
+}
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from rsrc + voff (per lane) to LDS bytes lds_addr .. + 1023, lane-linear
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, int voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+
+// [rows][192 B] image (Q / dO slice, K block): 16-byte chunk ch of a row sits at chunk ch ^ ((row >> 2) & 3) - conflict-free
+// for the b128 row reads of the 32x32x16 A operand and for the transposed reads of both MFMA shapes (tools/exp/lds_banks.py)
+constexpr int ROWB = 192;
+__device__ __forceinline__ int img_off(int row, int ch) { return row * ROWB + 16 * (ch ^ ((row >> 2) & 3)); }
+// dS^T image [256 keys][32 queries] bf16, 64-byte rows, 8-byte slot s at slot s ^ ((row >> 1) & 7)
+__device__ __forceinline__ int dst_off(int row, int slot) { return row * 64 + 8 * (slot ^ ((row >> 1) & 7)); }
+
+__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_p;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(p));
+}
+__device__ __forceinline__ bf16x8 cat(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int t) {
+  return bf16x8{(bf16_t)x[8 * t], (bf16_t)x[8 * t + 1], (bf16_t)x[8 * t + 2], (bf16_t)x[8 * t + 3],
+                (bf16_t)x[8 * t + 4], (bf16_t)x[8 * t + 5], (bf16_t)x[8 * t + 6], (bf16_t)x[8 * t + 7]};
+}
+
+constexpr int KB = 256;        // keys per block
+constexpr int QS = 32;         // queries per slice
+constexpr int MAX_TQ = 2048;   // statistics of every query stay in LDS
+
+template <int DH> struct Lds {
+  static constexpr int CH = DH / 8;                       // 16-byte chunks per row
+  static constexpr int KIMG = 0, KIMG_B = KB * ROWB;
+  static constexpr int QS0 = KIMG + KIMG_B, SLICE_B = QS * ROWB;
+  static constexpr int DO0 = QS0 + 2 * SLICE_B;
+  static constexpr int DST0 = DO0 + 2 * SLICE_B, DST_B = KB * 64;
+  static constexpr int KW0 = DST0 + 2 * DST_B;            // [4 waves][2 blk][32 q] u32
+  static constexpr int STAT0 = KW0 + 4 * 2 * 32 * 4;      // lse2 [Tqp], delta [Tqp]
+  static int bytes(int tqp) { return STAT0 + 2 * tqp * 4; }
+};
+
+template <int DH, bool DROP>
+__global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
+  typedef Lds<DH> L;
+  constexpr int KS = DH / 16;       // k-steps of a product over d (32x32x16)
+  constexpr int DB = DH / 32;       // 32-wide d blocks of dK^T / dV^T
+  constexpr int NT = DH / 32;       // 16-wide d blocks of dQ per wave (DH/16 blocks over the two wave pairs)
+  constexpr int CH = DH / 8;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, g = lane >> 5;
+  const int G = lane >> 4, qq = (lane & 15) >> 2, p4 = lane & 3;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int Tq = a.Tq, Tk = a.Tk;
+  const int nslice = (Tq + QS - 1) / QS, tqp = nslice * QS;
+  float* lse2_s = reinterpret_cast<float*>(smem + L::STAT0);
+  float* del_s = lse2_s + tqp;
+  uint32_t* kw_s = reinterpret_cast<uint32_t*>(smem + L::KW0) + w * 64;
+  typedef __attribute__((address_space(3))) char* lds_cp;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_cp)smem;            // LDS byte address of the dynamic segment
+
+  const bf16_t* qg = a.q + (int64_t)b * a.bsq + h * DH;
+  const bf16_t* kg = a.k + (int64_t)b * a.bsk + h * DH;
+  const bf16_t* vg = a.v + (int64_t)b * a.bsv + h * DH;
+  const bf16_t* og = a.o + (int64_t)b * a.bso + h * DH;
+  const bf16_t* dog = a.d_o + (int64_t)b * a.bso + h * DH;
+  const float unit = 1.4426950408889634f, cs = a.qscale * unit;
+  const int len = a.keypad ? a.len_k[b] : Tk;
+  const int kv_end = (a.keypad && len > 0 && len < Tk) ? len : Tk;      // keys at and beyond it get exactly zero weight
+  const int nkb = (kv_end + KB - 1) / KB;
+
+  // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O)
+  for (int q = tid; q < tqp; q += 256) {
+    float l2 = INFINITY, d = 0.f;
+    if (q < Tq) {
+      l2 = a.lse[(int64_t)bh * Tq + q] * unit;
+      const bf16x8* po = reinterpret_cast<const bf16x8*>(og + (int64_t)q * a.ldo);
+      const bf16x8* pd = reinterpret_cast<const bf16x8*>(dog + (int64_t)q * a.ldo);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const bf16x8 x = po[i], y = pd[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
+      }
+      a.delta[(int64_t)bh * Tq + q] = d;
+    }
+    lse2_s[q] = l2;
+    del_s[q] = d;
+  }
+
+  const u32x4 rs_q = make_rsrc(qg, (unsigned)(((int64_t)(Tq - 1) * a.ldq + DH) * 2));
+  const u32x4 rs_do = make_rsrc(dog, (unsigned)(((int64_t)(Tq - 1) * a.ldo + DH) * 2));
+  const u32x4 rs_k = make_rsrc(kg, (unsigned)(((int64_t)(Tk - 1) * a.ldk + DH) * 2));
+  // slice image = QS * CH chunks; LDS slot n (16 B) = lane + 64 * (w + 4 * i) holds chunk (n % CH) ^ swizzle of row n / CH
+  auto issue_slice = [&](int sl) __attribute__((always_inline)) {
+    const int buf = sl & 1;
+#pragma unroll
+    for (int i = 0; i < (QS * CH + 255) / 256; ++i) {
+      const int n = tid + 256 * i;
+      if (n - lane < QS * CH) {                                           // wave-uniform
+        const int row = n / CH, ch = (n % CH) ^ ((row >> 2) & 3);
+        const int qrow = sl * QS + row;
+        const unsigned dst = (unsigned)(w + 4 * i) * 1024u;
+        dma16(rs_q, lds_base + L::QS0 + buf * L::SLICE_B + dst, (int)(qrow * a.ldq * 2 + ch * 16));
+        dma16(rs_do, lds_base + L::DO0 + buf * L::SLICE_B + dst, (int)(qrow * a.ldo * 2 + ch * 16));
+      }
+    }
+  };
+  // keep words of slice sl for this wave's two key columns: lane c < 32 fetches the pair of query sl*32 + c
+  auto load_kw = [&](int sl, int kb) -> u32x2 {
+    u32x2 r = {0u, 0u};
+    if constexpr (DROP) {
+      const int q = sl * QS + c, wi = kb * (KB / 32) + 2 * w;
+      if (q < Tq && sl < nslice) {
+        const uint32_t* pw = a.keep + ((int64_t)bh * Tq + q) * a.nw + wi;
+        if (wi < a.nw) r[0] = pw[0];
+        if (wi + 1 < a.nw) r[1] = pw[1];
+      }
+    }
+    return r;
+  };
+
+  const int dq_qh = w & 1, dq_d0 = (w >> 1) * (NT * 16);                  // this wave's part of a dQ slice: 16 queries x NT*16 columns
+
+  // ---- lane constants of the LDS addressing; every read below is one of these plus a compile-time offset
+  // row reads (b128) of a [row][192 B] image, row = 32 m + c, chunk 2 ks + g = 4 (ks >> 1) + (2 (ks & 1) + g)
+  const int sw_c = (c >> 2) & 3;
+  const int rrd0 = c * ROWB + 16 * (g ^ sw_c), rrd1 = c * ROWB + 16 * ((2 + g) ^ sw_c);
+  // transposed reads of a slice image for the 32x32x16 A operand: row 16 t + 4 g + qq (+ 8), chunk 4 db + 2 (G & 1) + (p4 >> 1)
+  const int trs_lo = (4 * g + qq) * ROWB + 16 * ((2 * (G & 1) + (p4 >> 1)) ^ g) + 8 * (p4 & 1);
+  const int trs_hi = (4 * g + qq + 8) * ROWB + 16 * ((2 * (G & 1) + (p4 >> 1)) ^ (g + 2)) + 8 * (p4 & 1);
+  // transposed reads of the dS^T image for the 16x16x32 A operand: row 32 kk + 8 G + qq (+ 4), slot 4 qh + p4
+  const int trd_lo = dst_off(8 * G + qq, 4 * dq_qh + p4), trd_hi = dst_off(8 * G + qq + 4, 4 * dq_qh + p4);
+  // transposed reads of the K image for the 16x16x32 B operand: row 32 kk + 8 G + qq (+ 4), chunk dq_d0 / 8 + 2 n + (p4 >> 1)
+  int trk_lo[NT], trk_hi[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    trk_lo[n] = img_off(8 * G + qq, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
+    trk_hi[n] = img_off(8 * G + qq + 4, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
+  }
+  // dS^T stores: key row 64 w + 32 blk + c, slot 2 j + g
+  const int krow = 64 * w + c;
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int K0 = kb * KB;
+    __syncthreads();                                                      // previous pass has left the K image and the staging buffers
+    // ---- K image of the block by LDS-DMA
+#pragma unroll
+    for (int i = 0; i < KB * CH / 256; ++i) {
+      const int n = tid + 256 * i, row = n / CH, ch = (n % CH) ^ ((row >> 2) & 3);
+      dma16(rs_k, lds_base + L::KIMG + (unsigned)(w + 4 * i) * 1024u, (int)((K0 + row) * a.ldk * 2 + ch * 16));
+    }
+    issue_slice(0);
+    // ---- V fragments of this wave's 64 keys (B operands: column = key, k = 16 ks + 8 g + j); K fragments come from the image
+    bf16x8 vf[2][KS];
+    float kbias[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int key = K0 + 64 * w + 32 * blk + c;
+      const bool ok = key < Tk;
+      const int kc = ok ? key : Tk - 1;
+      const bf16x8 zero = {};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vg + (int64_t)kc * a.ldv + 16 * ks + 8 * g);
+        vf[blk][ks] = ok ? vv : zero;
+      }
+      kbias[blk] = !ok ? -INFINITY : ((a.keypad && key >= len) ? NEG_BIAS * unit : 0.f);
+    }
+    f32x16 dk[2][DB], dv[2][DB];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { dk[blk][db][v] = 0.f; dv[blk][db][v] = 0.f; }
+    u32x2 kw_next = load_kw(0, kb);
+    const bool first = kb == 0, last = kb == nkb - 1;
+
+    // dQ of slice sl from dsT[sl & 1] and the K image; added to / stored over the partial sums (rows padded to the slice)
+    auto dq_slice = [&](int sl) __attribute__((always_inline)) {
+      const char* dst = smem + L::DST0 + (sl & 1) * L::DST_B;
+      const char* kim = smem + L::KIMG;
+      f32x4 acc[NT];
+      const int q_base = sl * QS + 16 * dq_qh + 4 * G;                   // + r: the four queries of this lane's accumulator registers
+      float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (lane & 15);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!first) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[n][r] = wsp[r * DH + 16 * n];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KB / 32; ++kk) {
+        const bf16x8 af = cat(lds_tr(dst + trd_lo + kk * 32 * 64), lds_tr(dst + trd_hi + kk * 32 * 64));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const bf16x8 bfr = cat(lds_tr(kim + trk_lo[n] + kk * 32 * ROWB), lds_tr(kim + trk_hi[n] + kk * 32 * ROWB));
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n], 0, 0, 0);
+        }
+        FENCE();
+      }
+      if (last) {
+        bf16_t* dqp = a.dq + ((int64_t)b * Tq + q_base) * a.lddq + h * DH + dq_d0 + (lane & 15);
+        if (sl * QS + QS <= Tq) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dqp[r * a.lddq + 16 * n] = (bf16_t)(acc[n][r] * a.qscale);
+        } else {
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (q_base + r < Tq) dqp[r * a.lddq + 16 * n] = (bf16_t)(acc[n][r] * a.qscale);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wsp[r * DH + 16 * n] = acc[n][r];
+      }
+    };
+
+    for (int sl = 0; sl < nslice; ++sl) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's DMA pieces of slice sl (and of the K image) have landed
+      __syncthreads();
+      if (sl + 1 < nslice) issue_slice(sl + 1);
+      // keep words: this wave's [2 blk][32 q] table, written by the lanes that fetched them one slice ahead
+      if constexpr (DROP) {
+        if (lane < 32) { kw_s[c] = kw_next[0]; kw_s[32 + c] = kw_next[1]; }
+        kw_next = load_kw(sl + 1, kb);
+      }
+      const char* qs = smem + L::QS0 + (sl & 1) * L::SLICE_B;
+      const char* dos = smem + L::DO0 + (sl & 1) * L::SLICE_B;
+      const char* kim = smem + L::KIMG + (64 * w) * ROWB;
+      // ---- S = Q.K^T, dP = dO.V^T for both key columns
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { s[blk][v] = 0.f; dp[blk][v] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ro = ((ks & 1) ? rrd1 : rrd0) + 64 * (ks >> 1);
+        const bf16x8 aq = *reinterpret_cast<const bf16x8*>(qs + ro);
+        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(dos + ro);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kim + ro + 32 * blk * ROWB);
+          s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kfr, s[blk], 0, 0, 0);
+          dp[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[blk][ks], dp[blk], 0, 0, 0);
+        }
+        FENCE();
+      }
+      // ---- dQ of the previous slice: independent matrix work beside the vector work below
+      if (sl > 0) dq_slice(sl - 1);
+      // ---- P and dS in registers
+      bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2_s + sl * QS + 8 * j + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sl * QS + 8 * j + 4 * g);
+          u32x4 k4 = {0u, 0u, 0u, 0u};
+          if constexpr (DROP) k4 = *reinterpret_cast<const u32x4*>(kw_s + 32 * blk + 8 * j + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int v = 4 * j + r;
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[blk][v], cs, kbias[blk] - l4[r]));
+            float pd = p;
+            if constexpr (DROP) {
+              const int m = __builtin_amdgcn_sbfe(k4[r], c, 1);          // 0 or -1 from bit c
+              pd = __builtin_bit_cast(float, __builtin_bit_cast(int, p) & m);
+            }
+            const float t = p * d4[r];
+            s[blk][v] = pd;
+            dp[blk][v] = DROP ? __builtin_fmaf(pd * dp[blk][v], a.keep_scale, -t) : __builtin_fmaf(p, dp[blk][v], -t);
+          }
+          FENCE();
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { pf[blk][t] = pack8(s[blk], t); dsf[blk][t] = pack8(dp[blk], t); }
+      }
+      // ---- dS^T into LDS for the dQ product of the next iteration: key row, queries 8 j + 4 g .. + 3 = slot 2 j + g
+      {
+        char* dst = smem + L::DST0 + (sl & 1) * L::DST_B;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bf16x4 d4 = {dsf[blk][j >> 1][4 * (j & 1)], dsf[blk][j >> 1][4 * (j & 1) + 1], dsf[blk][j >> 1][4 * (j & 1) + 2],
+                               dsf[blk][j >> 1][4 * (j & 1) + 3]};
+            *reinterpret_cast<bf16x4*>(dst + dst_off(krow + 32 * blk, 2 * j + g)) = d4;
+          }
+        }
+      }
+      // ---- dV^T += dO^T.P, dK^T += Q^T.dS: A = transposed reads, rows 16 t + 4 g + q (+ 8), columns 32 db + 16 (G & 1) + 4 p
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const int o2 = 16 * t * ROWB + 64 * db;
+          const bf16x8 adt = cat(lds_tr(dos + trs_lo + o2), lds_tr(dos + trs_hi + o2));
+          const bf16x8 aqt = cat(lds_tr(qs + trs_lo + o2), lds_tr(qs + trs_hi + o2));
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            dv[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adt, pf[blk][t], dv[blk][db], 0, 0, 0);
+            dk[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqt, dsf[blk][t], dk[blk][db], 0, 0, 0);
+          }
+          FENCE();
+        }
+    }
+    __syncthreads();
+    dq_slice(nslice - 1);
+    __syncthreads();                                                      // every wave is done with the K image: it becomes the store staging area
+    // ---- dK, dV of this wave's 64 keys: registers -> [64][DH] bf16 tile in LDS -> whole rows to memory
+    {
+      char* st = smem + L::KIMG + w * (64 * ROWB);
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float sc = which == 0 ? a.qscale : (DROP ? a.keep_scale : 1.f);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x16& x = which == 0 ? dk[blk][db] : dv[blk][db];
+              const bf16x4 o4 = {(bf16_t)(x[4 * j] * sc), (bf16_t)(x[4 * j + 1] * sc), (bf16_t)(x[4 * j + 2] * sc), (bf16_t)(x[4 * j + 3] * sc)};
+              *reinterpret_cast<bf16x4*>(st + (32 * blk + c) * ROWB + (32 * db + 8 * j + 4 * g) * 2) = o4;
+            }
+        bf16_t* outp = which == 0 ? a.dk : a.dv;
+        const int64_t ldo = which == 0 ? a.lddk : a.lddv;
+#pragma unroll
+        for (int i = 0; i < 64 * CH / 64; ++i) {
+          const int n = lane + 64 * i, row = n / CH, ch = n % CH, key = K0 + 64 * w + row;
+          const bf16x8 val = *reinterpret_cast<const bf16x8*>(st + row * ROWB + ch * 16);
+          if (key < Tk) *reinterpret_cast<bf16x8*>(outp + ((int64_t)b * Tk + key) * ldo + h * DH + ch * 8) = val;
+        }
+      }
+    }
+  }
+  // ---- keys the passes did not visit (behind the valid length): exactly zero gradients
+  {
+    const bf16x8 zero = {};
+    const int k_first = nkb * KB;
+    for (int n = tid; n < (Tk - k_first) * CH; n += 256) {
+      const int key = k_first + n / CH, ch = n % CH;
+      *reinterpret_cast<bf16x8*>(a.dk + ((int64_t)b * Tk + key) * a.lddk + h * DH + ch * 8) = zero;
+      *reinterpret_cast<bf16x8*>(a.dv + ((int64_t)b * Tk + key) * a.lddv + h * DH + ch * 8) = zero;
+    }
+  }
+}
+
+}  // namespace a2
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static int g_opt_mha_fused = 1;           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
+int neurst_attention2_set_option(const char* name, int value) {
+  if (!strcmp(name, "mha_fused")) { g_opt_mha_fused = value; return 1; }
+  return 0;
+}
+
+
+extern "C" int64_t neurst_mha_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh) {
+  return Tk > a2::KB ? B * H * cdiv64(Tq, a2::QS) * a2::QS * dh * (int64_t)sizeof(float) : 0;   // query rows padded to whole slices
+}
+
+bool neurst_mha2_bwd_eligible(const Mha2Problem& p, int64_t ws_bytes) {
+  if (!g_opt_mha_fused || p.dtype != NEURST_BF16) return false;
+  if (p.dh != 96) return false;
+  if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
+  if (p.Tq > a2::MAX_TQ || p.B * p.H > 65535 * 16) return false;
+  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128)) return false;
+  if (ws_bytes < neurst_mha_bwd_workspace_bytes(p.B, p.H, p.Tq, p.Tk, p.dh)) return false;
+  auto al16 = [](const void* x, int64_t ld) { return ((uintptr_t)x & 15) == 0 && (ld * 2) % 16 == 0; };
+  if (!al16(p.q, p.ldq) || !al16(p.k, p.ldk) || !al16(p.v, p.ldv) || !al16(p.o, p.ldo) || !al16(p.d_o, p.ldo)) return false;
+  if (!al16(p.dk, p.lddk) || !al16(p.dv, p.lddv)) return false;
+  // 32-bit byte offsets inside one batch element's rows (LDS-DMA voffset)
+  if (p.Tq * p.ldq * 2 >= (1ll << 31) || p.Tk * p.ldk * 2 >= (1ll << 31) || p.Tq * p.ldo * 2 >= (1ll << 31)) return false;
+  if (p.rate > 0.f && !p.keep) return false;
+  return true;
+}
+
+int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
+  a2::Args a;
+  memset(&a, 0, sizeof(a));
+  a.q = (const bf16_t*)p.q; a.k = (const bf16_t*)p.k; a.v = (const bf16_t*)p.v; a.o = (const bf16_t*)p.o; a.d_o = (const bf16_t*)p.d_o;
+  a.dq = (bf16_t*)p.dq; a.dk = (bf16_t*)p.dk; a.dv = (bf16_t*)p.dv;
+  a.lse = p.lse; a.delta = p.delta; a.ws = ws; a.keep = p.rate > 0.f ? p.keep : nullptr; a.len_k = p.len_k;
+  a.ldq = p.ldq; a.ldk = p.ldk; a.ldv = p.ldv; a.ldo = p.ldo; a.lddq = p.lddq; a.lddk = p.lddk; a.lddv = p.lddv;
+  a.bsq = p.Tq * p.ldq; a.bsk = p.Tk * p.ldk; a.bsv = p.Tk * p.ldv; a.bso = p.Tq * p.ldo;
+  a.B = (int)p.B; a.H = (int)p.H; a.Tq = (int)p.Tq; a.Tk = (int)p.Tk; a.nw = (int)cdiv64(p.Tk, 32);
+  a.keypad = p.mask_mode == NEURST_MASK_KEYPAD;
+  a.qscale = 1.0f / sqrtf((float)p.dh);
+  a.keep_scale = keep_scale(p.rate);
+  const int tqp = (int)cdiv64(p.Tq, a2::QS) * a2::QS;
+  const size_t smem = a2::Lds<96>::bytes(tqp);
+  auto kern = p.rate > 0.f ? a2::mha2_bwd_kernel<96, true> : a2::mha2_bwd_kernel<96, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) { neurst_set_error("mha2_bwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
+  kern<<<dim3((unsigned)(p.B * p.H)), 256, smem, s>>>(a);
+  NEURST_CHECK_LAUNCH("mha2_bwd");
+  return NEURST_OK;
+}

@@ -274,8 +274,13 @@ def mha_fwd(q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, ke
 
 def mha_bwd(q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, len_k, rate, key, keep_bits=None):
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
-    _chk(_C.neurst_mha_bwd_train(_p(q), _p(k), _p(v), _p(o), _p(_c(d_o)), _p(lse), _p(keep_bits), _p(delta), _p(dq), _p(dk), _p(dv), ldq, ldk,
-                                  ldv, H * dh, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key, dt_of(q), _s()), 'mha_bwd')
+    # fp32 partial dQ of the fused kernel (encoder-size bf16 problems with more than one block of 256 keys); the caching
+    # allocator hands the same block back every layer
+    wsb = _C.neurst_mha_bwd_workspace_bytes(B, H, Tq, Tk, dh) if q.dtype == torch.bfloat16 else 0
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=q.device) if wsb else None
+    _chk(_C.neurst_mha_bwd_train_ws(_p(q), _p(k), _p(v), _p(o), _p(_c(d_o)), _p(lse), _p(keep_bits), _p(delta), _p(dq), _p(dk), _p(dv), ldq, ldk,
+                                     ldv, H * dh, lddq, lddk, lddv, B, H, Tq, Tk, dh, mask_mode, _p(len_k), rate, key, dt_of(q),
+                                     _p(ws), wsb, _s()), 'mha_bwd')
 
 
 # ---- layer norm ------------------------------------------------------------------------

@@ -16,25 +16,29 @@ int main(int argc, char** argv) {
   for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 16) & 0x807f) | 0x3f00 | ((s >> 9) & 0x0080)); }
   CK(hipMemcpy(qkv, h.data(), n * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(d_o, h.data(), n / 3 * 2, hipMemcpyHostToDevice));
   std::vector<int> hl(B, (int)T); CK(hipMemcpy(lens, hl.data(), B * 4, hipMemcpyHostToDevice));
+  unsigned short* keep; float* ws;
+  int64_t kbb = neurst_mha_keep_bits_bytes(B, H, T, T), wsb = neurst_mha_bwd_workspace_bytes(B, H, T, T, dh);
+  CK(hipMalloc(&keep, kbb)); CK(hipMalloc(&ws, wsb ? wsb : 16));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (float rate : {0.0f, 0.1f}) {
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 3; ++which) {
+      neurst_set_option("mha_fused", which == 2 ? 2 : 0);
       const int iters = 20;
       float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; ++i) {
           int rc = which == 0
-            ? neurst_mha_fwd(qkv, qkv + d, qkv + 2 * d, o, lse, 3 * d, 3 * d, 3 * d, d, B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, rate, 123u, NEURST_BF16, nullptr)
-            : neurst_mha_bwd(qkv, qkv + d, qkv + 2 * d, o, d_o, lse, delta, dqkv, dqkv + d, dqkv + 2 * d, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
-                             B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, rate, 123u, NEURST_BF16, nullptr);
+            ? neurst_mha_fwd_train(qkv, qkv + d, qkv + 2 * d, o, lse, rate > 0 ? keep : nullptr, 3 * d, 3 * d, 3 * d, d, B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, rate, 123u, NEURST_BF16, nullptr)
+            : neurst_mha_bwd_train_ws(qkv, qkv + d, qkv + 2 * d, o, d_o, lse, rate > 0 ? keep : nullptr, delta, dqkv, dqkv + d, dqkv + 2 * d, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
+                             B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, rate, 123u, NEURST_BF16, ws, wsb, nullptr);
           if (rc) { printf("error %s\n", neurst_last_error()); return 1; }
         }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
       double fl = 4.0 * B * H * T * T * dh * (which ? 2.5 : 1.0);
-      printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
+      printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which == 2 ? "bwd(fused) " : which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
     }
   }
   return 0;
