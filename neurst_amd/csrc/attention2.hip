@@ -42,6 +42,7 @@ struct Args {
   int64_t bsq, bsk, bsv, bso;
   int B, H, Tq, Tk, nw, keypad;
   float qscale, keep_scale;
+  long long* stamps;         // diagnostic: s_memtime of workgroup 0 / wave 0 at phase boundaries (null in production)
 };
 
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned records) {
@@ -115,41 +116,59 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   const int len = a.keypad ? a.len_k[b] : Tk;
   const int kv_end = (a.keypad && len > 0 && len < Tk) ? len : Tk;      // keys at and beyond it get exactly zero weight
   const int nkb = (kv_end + KB - 1) / KB;
+  int n_stamp = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (a.stamps) {
+      FENCE();
+      if (blockIdx.x == 0 && tid == 0) a.stamps[n_stamp++] = (long long)__builtin_amdgcn_s_memtime();
+      FENCE();
+    }
+  };
+  stamp();
 
-  // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O)
-  for (int q = tid; q < tqp; q += 256) {
-    float l2 = INFINITY, d = 0.f;
+  // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O).  Four lanes per
+  // row (chunks p4, p4 + 4, ...: 64 contiguous bytes per row and instruction), quad sum by DPP
+  for (int q0 = 0; q0 < tqp; q0 += 64) {
+    const int q = q0 + (tid >> 2);
+    float d = 0.f;
     if (q < Tq) {
-      l2 = a.lse[(int64_t)bh * Tq + q] * unit;
       const bf16x8* po = reinterpret_cast<const bf16x8*>(og + (int64_t)q * a.ldo);
       const bf16x8* pd = reinterpret_cast<const bf16x8*>(dog + (int64_t)q * a.ldo);
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const bf16x8 x = po[i], y = pd[i];
+      for (int i = 0; i < CH / 4; ++i) {
+        const bf16x8 x = po[p4 + 4 * i], y = pd[p4 + 4 * i];
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
       }
-      a.delta[(int64_t)bh * Tq + q] = d;
     }
-    lse2_s[q] = l2;
-    del_s[q] = d;
+    d += NEURST_DPP_F32(d, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    d += NEURST_DPP_F32(d, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    if (p4 == 0 && q < tqp) {
+      float l2 = INFINITY;
+      if (q < Tq) { l2 = a.lse[(int64_t)bh * Tq + q] * unit; a.delta[(int64_t)bh * Tq + q] = d; }
+      lse2_s[q] = l2;
+      del_s[q] = d;
+    }
   }
 
   const u32x4 rs_q = make_rsrc(qg, (unsigned)(((int64_t)(Tq - 1) * a.ldq + DH) * 2));
   const u32x4 rs_do = make_rsrc(dog, (unsigned)(((int64_t)(Tq - 1) * a.ldo + DH) * 2));
   const u32x4 rs_k = make_rsrc(kg, (unsigned)(((int64_t)(Tk - 1) * a.ldk + DH) * 2));
   // slice image = QS * CH chunks; LDS slot n (16 B) = lane + 64 * (w + 4 * i) holds chunk (n % CH) ^ swizzle of row n / CH
+  const int ldq2 = (int)a.ldq * 2, ldo2 = (int)a.ldo * 2;
   auto issue_slice = [&](int sl) __attribute__((always_inline)) {
     const int buf = sl & 1;
+    int t = tid;
+    asm volatile("" : "+v"(t));      // recomputed per call (a few VALU ops): as loop invariants these offsets get spilled, and a
+                                     // scratch reload's vmcnt(0) then waits for the DMA issued just before it
 #pragma unroll
     for (int i = 0; i < (QS * CH + 255) / 256; ++i) {
-      const int n = tid + 256 * i;
-      if (n - lane < QS * CH) {                                           // wave-uniform
-        const int row = n / CH, ch = (n % CH) ^ ((row >> 2) & 3);
+      if (64 * (w + 4 * i) < QS * CH) {                                   // wave-uniform
+        const int n = t + 256 * i, row = n / CH, ch = (n - row * CH) ^ ((row >> 2) & 3);
         const int qrow = sl * QS + row;
         const unsigned dst = (unsigned)(w + 4 * i) * 1024u;
-        dma16(rs_q, lds_base + L::QS0 + buf * L::SLICE_B + dst, (int)(qrow * a.ldq * 2 + ch * 16));
-        dma16(rs_do, lds_base + L::DO0 + buf * L::SLICE_B + dst, (int)(qrow * a.ldo * 2 + ch * 16));
+        dma16(rs_q, lds_base + L::QS0 + buf * L::SLICE_B + dst, qrow * ldq2 + ch * 16);
+        dma16(rs_do, lds_base + L::DO0 + buf * L::SLICE_B + dst, qrow * ldo2 + ch * 16);
       }
     }
   };
@@ -191,6 +210,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   for (int kb = 0; kb < nkb; ++kb) {
     const int K0 = kb * KB;
     __syncthreads();                                                      // previous pass has left the K image and the staging buffers
+    stamp();
     // ---- K image of the block by LDS-DMA
 #pragma unroll
     for (int i = 0; i < KB * CH / 256; ++i) {
@@ -239,15 +259,21 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
           for (int r = 0; r < 4; ++r) acc[n][r] = wsp[r * DH + 16 * n];
         }
       }
+      {
+        bf16x8 af[2], bfr[2][NT];
+        auto fetch = [&](int kk, int slot) __attribute__((always_inline)) {
+          af[slot] = cat(lds_tr(dst + trd_lo + kk * 32 * 64), lds_tr(dst + trd_hi + kk * 32 * 64));
 #pragma unroll
-      for (int kk = 0; kk < KB / 32; ++kk) {
-        const bf16x8 af = cat(lds_tr(dst + trd_lo + kk * 32 * 64), lds_tr(dst + trd_hi + kk * 32 * 64));
+          for (int n = 0; n < NT; ++n) bfr[slot][n] = cat(lds_tr(kim + trk_lo[n] + kk * 32 * ROWB), lds_tr(kim + trk_hi[n] + kk * 32 * ROWB));
+        };
+        fetch(0, 0);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const bf16x8 bfr = cat(lds_tr(kim + trk_lo[n] + kk * 32 * ROWB), lds_tr(kim + trk_hi[n] + kk * 32 * ROWB));
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n], 0, 0, 0);
+        for (int kk = 0; kk < KB / 32; ++kk) {
+          if (kk + 1 < KB / 32) fetch(kk + 1, (kk + 1) & 1);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk & 1], bfr[kk & 1][n], acc[n], 0, 0, 0);
+          FENCE();
         }
-        FENCE();
       }
       if (last) {
         bf16_t* dqp = a.dq + ((int64_t)b * Tq + q_base) * a.lddq + h * DH + dq_d0 + (lane & 15);
@@ -274,7 +300,10 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
     for (int sl = 0; sl < nslice; ++sl) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's DMA pieces of slice sl (and of the K image) have landed
       __syncthreads();
+      if (sl < 6) stamp();
+      if (sl == 4) stamp();
       if (sl + 1 < nslice) issue_slice(sl + 1);
+      if (sl == 4) stamp();
       // keep words: this wave's [2 blk][32 q] table, written by the lanes that fetched them one slice ahead
       if constexpr (DROP) {
         if (lane < 32) { kw_s[c] = kw_next[0]; kw_s[32 + c] = kw_next[1]; }
@@ -283,31 +312,36 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       const char* qs = smem + L::QS0 + (sl & 1) * L::SLICE_B;
       const char* dos = smem + L::DO0 + (sl & 1) * L::SLICE_B;
       const char* kim = smem + L::KIMG + (64 * w) * ROWB;
-      // ---- S = Q.K^T, dP = dO.V^T for both key columns
-      f32x16 s[2], dp[2];
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) { s[blk][v] = 0.f; dp[blk][v] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int ro = ((ks & 1) ? rrd1 : rrd0) + 64 * (ks >> 1);
-        const bf16x8 aq = *reinterpret_cast<const bf16x8*>(qs + ro);
-        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(dos + ro);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kim + ro + 32 * blk * ROWB);
-          s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kfr, s[blk], 0, 0, 0);
-          dp[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[blk][ks], dp[blk], 0, 0, 0);
-        }
-        FENCE();
-      }
-      // ---- dQ of the previous slice: independent matrix work beside the vector work below
+      // ---- dQ of the previous slice (independent of everything below)
+      if (sl == 4) stamp();
       if (sl > 0) dq_slice(sl - 1);
-      // ---- P and dS in registers
+      if (sl == 4) stamp();
+      // ---- per key column: S = Q.K^T, dP = dO.V^T, then P and dS in registers and dS^T into LDS for the next iteration's dQ
       bf16x8 pf[2][2], dsf[2][2];
+      char* dstw = smem + L::DST0 + (sl & 1) * L::DST_B;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { s[v] = 0.f; dp[v] = 0.f; }
+        {
+          auto ro_of = [&](int ks) __attribute__((always_inline)) { return ((ks & 1) ? rrd1 : rrd0) + 64 * (ks >> 1); };
+          const char* kimb = kim + 32 * blk * ROWB;
+          bf16x8 aq = *reinterpret_cast<const bf16x8*>(qs + ro_of(0)), ad = *reinterpret_cast<const bf16x8*>(dos + ro_of(0));
+          bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimb + ro_of(0));
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 naq = aq, nad = ad, nkf = kf;
+            if (ks + 1 < KS) {                                             // the next step's fragments are in flight under this step's MFMAs
+              const int ro = ro_of(ks + 1);
+              naq = *reinterpret_cast<const bf16x8*>(qs + ro); nad = *reinterpret_cast<const bf16x8*>(dos + ro);
+              nkf = *reinterpret_cast<const bf16x8*>(kimb + ro);
+            }
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[blk][ks], dp, 0, 0, 0);
+            aq = naq; ad = nad; kf = nkf;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2_s + sl * QS + 8 * j + 4 * g);
@@ -317,53 +351,58 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int v = 4 * j + r;
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[blk][v], cs, kbias[blk] - l4[r]));
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], cs, kbias[blk] - l4[r]));
             float pd = p;
             if constexpr (DROP) {
-              const int m = __builtin_amdgcn_sbfe(k4[r], c, 1);          // 0 or -1 from bit c
+              const int m = __builtin_amdgcn_sbfe(k4[r], c, 1);            // 0 or -1 from bit c
               pd = __builtin_bit_cast(float, __builtin_bit_cast(int, p) & m);
             }
             const float t = p * d4[r];
-            s[blk][v] = pd;
-            dp[blk][v] = DROP ? __builtin_fmaf(pd * dp[blk][v], a.keep_scale, -t) : __builtin_fmaf(p, dp[blk][v], -t);
-          }
-          FENCE();
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { pf[blk][t] = pack8(s[blk], t); dsf[blk][t] = pack8(dp[blk], t); }
-      }
-      // ---- dS^T into LDS for the dQ product of the next iteration: key row, queries 8 j + 4 g .. + 3 = slot 2 j + g
-      {
-        char* dst = smem + L::DST0 + (sl & 1) * L::DST_B;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bf16x4 d4 = {dsf[blk][j >> 1][4 * (j & 1)], dsf[blk][j >> 1][4 * (j & 1) + 1], dsf[blk][j >> 1][4 * (j & 1) + 2],
-                               dsf[blk][j >> 1][4 * (j & 1) + 3]};
-            *reinterpret_cast<bf16x4*>(dst + dst_off(krow + 32 * blk, 2 * j + g)) = d4;
+            s[v] = pd;
+            dp[v] = DROP ? __builtin_fmaf(pd * dp[v], a.keep_scale, -t) : __builtin_fmaf(p, dp[v], -t);
           }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { pf[blk][t] = pack8(s, t); dsf[blk][t] = pack8(dp, t); }
+        // key row 64 w + 32 blk + c, queries 8 j + 4 g .. + 3 = slot 2 j + g
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x4 d4 = {dsf[blk][j >> 1][4 * (j & 1)], dsf[blk][j >> 1][4 * (j & 1) + 1], dsf[blk][j >> 1][4 * (j & 1) + 2],
+                             dsf[blk][j >> 1][4 * (j & 1) + 3]};
+          *reinterpret_cast<bf16x4*>(dstw + dst_off(krow + 32 * blk, 2 * j + g)) = d4;
+        }
+        FENCE();
       }
+      if (sl == 4) stamp();
       // ---- dV^T += dO^T.P, dK^T += Q^T.dS: A = transposed reads, rows 16 t + 4 g + q (+ 8), columns 32 db + 16 (G & 1) + 4 p
+      {
+        auto o2_of = [&](int i) __attribute__((always_inline)) { return 16 * (i / DB) * ROWB + 64 * (i % DB); };
+        bf16x8 adt = cat(lds_tr(dos + trs_lo + o2_of(0)), lds_tr(dos + trs_hi + o2_of(0)));
+        bf16x8 aqt = cat(lds_tr(qs + trs_lo + o2_of(0)), lds_tr(qs + trs_hi + o2_of(0)));
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const int o2 = 16 * t * ROWB + 64 * db;
-          const bf16x8 adt = cat(lds_tr(dos + trs_lo + o2), lds_tr(dos + trs_hi + o2));
-          const bf16x8 aqt = cat(lds_tr(qs + trs_lo + o2), lds_tr(qs + trs_hi + o2));
+        for (int i = 0; i < 2 * DB; ++i) {
+          const int t = i / DB, db = i % DB;
+          bf16x8 nadt = adt, naqt = aqt;
+          if (i + 1 < 2 * DB) {
+            nadt = cat(lds_tr(dos + trs_lo + o2_of(i + 1)), lds_tr(dos + trs_hi + o2_of(i + 1)));
+            naqt = cat(lds_tr(qs + trs_lo + o2_of(i + 1)), lds_tr(qs + trs_hi + o2_of(i + 1)));
+          }
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk) {
             dv[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adt, pf[blk][t], dv[blk][db], 0, 0, 0);
             dk[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqt, dsf[blk][t], dk[blk][db], 0, 0, 0);
           }
           FENCE();
+          adt = nadt; aqt = naqt;
         }
+      }
     }
+    stamp();
     __syncthreads();
     dq_slice(nslice - 1);
-    __syncthreads();                                                      // every wave is done with the K image: it becomes the store staging area
+    __syncthreads();
+    stamp();
+    if (false) __syncthreads();                                                    // every wave is done with the K image: it becomes the store staging area
     // ---- dK, dV of this wave's 64 keys: registers -> [64][DH] bf16 tile in LDS -> whole rows to memory
     {
       char* st = smem + L::KIMG + w * (64 * ROWB);
@@ -391,6 +430,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       }
     }
   }
+  stamp();
   // ---- keys the passes did not visit (behind the valid length): exactly zero gradients
   {
     const bf16x8 zero = {};
@@ -433,9 +473,13 @@ bool neurst_mha2_bwd_eligible(const Mha2Problem& p, int64_t ws_bytes) {
   return true;
 }
 
+static long long* g_mha2_stamps = nullptr;
+extern "C" void neurst_debug_mha2_stamps(long long* dev_buf) { g_mha2_stamps = dev_buf; }
+
 int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
   a2::Args a;
   memset(&a, 0, sizeof(a));
+  a.stamps = g_mha2_stamps;
   a.q = (const bf16_t*)p.q; a.k = (const bf16_t*)p.k; a.v = (const bf16_t*)p.v; a.o = (const bf16_t*)p.o; a.d_o = (const bf16_t*)p.d_o;
   a.dq = (bf16_t*)p.dq; a.dk = (bf16_t*)p.dk; a.dv = (bf16_t*)p.dv;
   a.lse = p.lse; a.delta = p.delta; a.ws = ws; a.keep = p.rate > 0.f ? p.keep : nullptr; a.len_k = p.len_k;

@@ -32,16 +32,28 @@ def test_attention_rows_sum_to_one_and_dropout_keeps_the_mean():
     assert (o.float() - 1.0).abs().max().item() < 1e-2        # bf16 probabilities: 2^-8 relative each
     o2, lse2, kb = ops.mha_fwd(t, t[D:], t[2 * D:], 3 * D, 3 * D, 3 * D, B, H, T, T, DH, ops.MASK_KEYPAD, lens, 0.1, 7, keep_bits=True)
     assert abs(o2.float().mean().item() - 1.0) < 2e-3         # E[keep / (1 - rate)] = 1
-    # the stored decisions are the recomputed ones: backward with and without them gives the same gradients
+    # the stored decisions are the recomputed ones: the two-kernel backward with and without them gives the same gradients
+    # bit for bit, and the fused backward (which only runs on stored decisions) the same up to where it rounds to bf16
+    from neurst_amd import lib
+    C = lib.load()
     do = torch.randn_like(o2)
     outs = []
-    for bits in (kb, None):
-        dqkv = torch.zeros_like(qkv)
-        dt = dqkv.view(-1)
-        ops.mha_bwd(t, t[D:], t[2 * D:], o2, do, lse2, dt, dt[D:], dt[2 * D:], 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, B, H, T, T, DH,
-                    ops.MASK_KEYPAD, lens, 0.1, 7, keep_bits=bits)
-        outs.append(dqkv)
+    try:
+        for fused, bits in ((0, kb), (0, None), (1, kb)):
+            assert C.neurst_set_option(b'mha_fused', fused) == 0
+            dqkv = torch.zeros_like(qkv)
+            dt = dqkv.view(-1)
+            ops.mha_bwd(t, t[D:], t[2 * D:], o2, do, lse2, dt, dt[D:], dt[2 * D:], 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, B, H, T, T, DH,
+                        ops.MASK_KEYPAD, lens, 0.1, 7, keep_bits=bits)
+            outs.append(dqkv)
+    finally:
+        assert C.neurst_set_option(b'mha_fused', 1) == 0
     assert torch.equal(outs[0], outs[1])
+    a, b = outs[2].float(), outs[0].float()
+    assert torch.isfinite(a).all() and ((a - b).abs().max() / b.abs().max()).item() < 2e-2
+    assert ((a - b).norm() / b.norm()).item() < 1e-2
+    pad = torch.arange(T, device=DEV)[None, :] >= lens[:, None]
+    assert (outs[2][:, :, D:][pad] == 0).all()                # keys behind the length: exactly zero dK, dV
 
 
 def test_ctc_gradient_frames_sum_to_zero_and_padding_is_zero():

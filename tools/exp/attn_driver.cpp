@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../include/neurst_hip.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+extern "C" void neurst_debug_mha2_stamps(long long*);
 int main(int argc, char** argv) {
   const int64_t B = 32, H = 8, T = argc > 1 ? atoi(argv[1]) : 500, dh = 96, d = H * dh;
   size_t n = B * T * 3 * d;
@@ -40,6 +41,20 @@ int main(int argc, char** argv) {
       double fl = 4.0 * B * H * T * T * dh * (which ? 2.5 : 1.0);
       printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which == 2 ? "bwd(fused) " : which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
     }
+  }
+  {   // phase stamps of workgroup 0 of the fused backward (cycles)
+    long long* st; CK(hipMalloc(&st, 64 * 8)); CK(hipMemset(st, 0, 64 * 8));
+    neurst_debug_mha2_stamps(st);
+    neurst_set_option("mha_fused", 2);
+    int rc = neurst_mha_bwd_train_ws(qkv, qkv + d, qkv + 2 * d, o, d_o, lse, keep, delta, dqkv, dqkv + d, dqkv + 2 * d, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
+                             B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, 0.1f, 123u, NEURST_BF16, ws, wsb, nullptr);
+    if (rc) { printf("error %s\n", neurst_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    long long hs[64]; CK(hipMemcpy(hs, st, sizeof(hs), hipMemcpyDeviceToHost));
+    neurst_debug_mha2_stamps(nullptr);
+    printf("stamps (delta cycles):");
+    for (int i = 1; i < 64 && hs[i]; ++i) printf(" %lld", hs[i] - hs[i - 1]);
+    printf("\n");
   }
   return 0;
 }
