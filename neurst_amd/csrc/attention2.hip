@@ -88,7 +88,7 @@ template <int DH> struct Lds {
   static int bytes(int tqp) { return STAT0 + 2 * tqp * 4; }
 };
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool STAMPS>
 __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   typedef Lds<DH> L;
   constexpr int KS = DH / 16;       // k-steps of a product over d (32x32x16)
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   const int nkb = (kv_end + KB - 1) / KB;
   int n_stamp = 0;
   auto stamp = [&]() __attribute__((always_inline)) {
-    if (a.stamps) {
+    if constexpr (STAMPS) {
       FENCE();
       if (blockIdx.x == 0 && tid == 0) a.stamps[n_stamp++] = (long long)__builtin_amdgcn_s_memtime();
       FENCE();
@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   stamp();
 
   // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O).  Four lanes per
-  // row (chunks p4, p4 + 4, ...: 64 contiguous bytes per row and instruction), quad sum by DPP
+  // row (chunks p4, p4 + 4, ...: 64 contiguous bytes per row and instruction), quad sum by DPP.  (Streaming them one
+  // slice ahead inside the first pass instead was measured: the burst only moves into the loop, no gain.)
   for (int q0 = 0; q0 < tqp; q0 += 64) {
     const int q = q0 + (tid >> 2);
     float d = 0.f;
@@ -172,16 +173,15 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       }
     }
   };
-  // keep words of slice sl for this wave's two key columns: lane c < 32 fetches the pair of query sl*32 + c
-  auto load_kw = [&](int sl, int kb) -> u32x2 {
-    u32x2 r = {0u, 0u};
+  // keep words of slice sl for this wave's two key columns: lane (c, g) fetches word g of query sl * 32 + c (zero beyond the tensor)
+  auto load_kw = [&](int sl, int kb) -> uint32_t {
+    uint32_t r = 0u;
     if constexpr (DROP) {
-      const int q = sl * QS + c, wi = kb * (KB / 32) + 2 * w;
-      if (q < Tq && sl < nslice) {
-        const uint32_t* pw = a.keep + ((int64_t)bh * Tq + q) * a.nw + wi;
-        if (wi < a.nw) r[0] = pw[0];
-        if (wi + 1 < a.nw) r[1] = pw[1];
-      }
+      const int q = sl * QS + c, wi = kb * (KB / 32) + 2 * w + g;
+      const bool ok = q < Tq && wi < a.nw;
+      const uint32_t* pw = a.keep + ((int64_t)bh * Tq + (ok ? q : 0)) * a.nw + (ok ? wi : 0);
+      r = *pw;
+      r = ok ? r : 0u;
     }
     return r;
   };
@@ -241,39 +241,45 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int v = 0; v < 16; ++v) { dk[blk][db][v] = 0.f; dv[blk][db][v] = 0.f; }
-    u32x2 kw_next = load_kw(0, kb);
+    uint32_t kw_next = load_kw(0, kb);
     const bool first = kb == 0, last = kb == nkb - 1;
 
-    // dQ of slice sl from dsT[sl & 1] and the K image; added to / stored over the partial sums (rows padded to the slice)
-    auto dq_slice = [&](int sl) __attribute__((always_inline)) {
+    // dQ of slice sl from dsT[sl & 1] and the K image, in KB / 32 k-steps that the slice loop places between the groups of
+    // its vector work; added to / stored over the partial sums (workspace rows padded to whole slices)
+    f32x4 dqa[NT], dqw[NT];
+    bf16x8 dq_af[2], dq_bf[2][NT];
+    auto dq_fetch = [&](int sl, int kk) __attribute__((always_inline)) {
       const char* dst = smem + L::DST0 + (sl & 1) * L::DST_B;
-      const char* kim = smem + L::KIMG;
-      f32x4 acc[NT];
+      const char* kimq = smem + L::KIMG;
+      dq_af[kk & 1] = cat(lds_tr(dst + trd_lo + kk * 32 * 64), lds_tr(dst + trd_hi + kk * 32 * 64));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) dq_bf[kk & 1][n] = cat(lds_tr(kimq + trk_lo[n] + kk * 32 * ROWB), lds_tr(kimq + trk_hi[n] + kk * 32 * ROWB));
+    };
+    // the partial sums of the earlier passes: loaded FIRST in an iteration (older than the DMA pieces issued after them, so
+    // the wait for them leaves those in flight) and added after the last k-step
+    auto dq_load_partial = [&](int sl) __attribute__((always_inline)) {
       const int q_base = sl * QS + 16 * dq_qh + 4 * G;                   // + r: the four queries of this lane's accumulator registers
-      float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (lane & 15);
+      const float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (lane & 15);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!first) {
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[n][r] = wsp[r * DH + 16 * n];
-        }
-      }
-      {
-        bf16x8 af[2], bfr[2][NT];
-        auto fetch = [&](int kk, int slot) __attribute__((always_inline)) {
-          af[slot] = cat(lds_tr(dst + trd_lo + kk * 32 * 64), lds_tr(dst + trd_hi + kk * 32 * 64));
+        for (int r = 0; r < 4; ++r) dqw[n][r] = wsp[r * DH + 16 * n];
+    };
+    auto dq_begin = [&](int sl) __attribute__((always_inline)) {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bfr[slot][n] = cat(lds_tr(kim + trk_lo[n] + kk * 32 * ROWB), lds_tr(kim + trk_hi[n] + kk * 32 * ROWB));
-        };
-        fetch(0, 0);
+      for (int n = 0; n < NT; ++n) dqa[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dq_fetch(sl, 0);
+    };
+    auto dq_step = [&](int sl, int kk) __attribute__((always_inline)) {
+      if (kk + 1 < KB / 32) dq_fetch(sl, kk + 1);
 #pragma unroll
-        for (int kk = 0; kk < KB / 32; ++kk) {
-          if (kk + 1 < KB / 32) fetch(kk + 1, (kk + 1) & 1);
+      for (int n = 0; n < NT; ++n) dqa[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dq_af[kk & 1], dq_bf[kk & 1][n], dqa[n], 0, 0, 0);
+    };
+    auto dq_end = [&](int sl) __attribute__((always_inline)) {
+      const int q_base = sl * QS + 16 * dq_qh + 4 * G;
+      if (!first) {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk & 1], bfr[kk & 1][n], acc[n], 0, 0, 0);
-          FENCE();
-        }
+        for (int n = 0; n < NT; ++n) dqa[n] += dqw[n];
       }
       if (last) {
         bf16_t* dqp = a.dq + ((int64_t)b * Tq + q_base) * a.lddq + h * DH + dq_d0 + (lane & 15);
@@ -281,19 +287,20 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
 #pragma unroll
           for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dqp[r * a.lddq + 16 * n] = (bf16_t)(acc[n][r] * a.qscale);
+            for (int r = 0; r < 4; ++r) dqp[r * a.lddq + 16 * n] = (bf16_t)(dqa[n][r] * a.qscale);
         } else {
 #pragma unroll
           for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (q_base + r < Tq) dqp[r * a.lddq + 16 * n] = (bf16_t)(acc[n][r] * a.qscale);
+              if (q_base + r < Tq) dqp[r * a.lddq + 16 * n] = (bf16_t)(dqa[n][r] * a.qscale);
         }
       } else {
+        float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (lane & 15);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) wsp[r * DH + 16 * n] = acc[n][r];
+          for (int r = 0; r < 4; ++r) wsp[r * DH + 16 * n] = dqa[n][r];
       }
     };
 
@@ -301,20 +308,20 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's DMA pieces of slice sl (and of the K image) have landed
       __syncthreads();
       if (sl < 6) stamp();
-      if (sl == 4) stamp();
+      const int slq = sl > 0 ? sl - 1 : 0;
+      if (!first) dq_load_partial(slq);
       if (sl + 1 < nslice) issue_slice(sl + 1);
-      if (sl == 4) stamp();
       // keep words: this wave's [2 blk][32 q] table, written by the lanes that fetched them one slice ahead
       if constexpr (DROP) {
-        if (lane < 32) { kw_s[c] = kw_next[0]; kw_s[32 + c] = kw_next[1]; }
+        kw_s[lane] = kw_next;
         kw_next = load_kw(sl + 1, kb);
       }
       const char* qs = smem + L::QS0 + (sl & 1) * L::SLICE_B;
       const char* dos = smem + L::DO0 + (sl & 1) * L::SLICE_B;
       const char* kim = smem + L::KIMG + (64 * w) * ROWB;
-      // ---- dQ of the previous slice (independent of everything below)
-      if (sl == 4) stamp();
-      if (sl > 0) dq_slice(sl - 1);
+      // dQ of the previous slice runs as filler: its k-steps sit between the groups of vector work below (at sl == 0 it
+      // multiplies whatever the buffer holds and the result is dropped)
+      dq_begin(slq);
       if (sl == 4) stamp();
       // ---- per key column: S = Q.K^T, dP = dO.V^T, then P and dS in registers and dS^T into LDS for the next iteration's dQ
       bf16x8 pf[2][2], dsf[2][2];
@@ -327,27 +334,33 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
         {
           auto ro_of = [&](int ks) __attribute__((always_inline)) { return ((ks & 1) ? rrd1 : rrd0) + 64 * (ks >> 1); };
           const char* kimb = kim + 32 * blk * ROWB;
-          bf16x8 aq = *reinterpret_cast<const bf16x8*>(qs + ro_of(0)), ad = *reinterpret_cast<const bf16x8*>(dos + ro_of(0));
-          bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimb + ro_of(0));
+          // fragments two k-steps ahead: a step's two MFMAs (64 cycles) are shorter than an LDS round trip
+          bf16x8 aq[3], ad[3], kf[3];
+          auto fetch = [&](int ks) __attribute__((always_inline)) {
+            const int ro = ro_of(ks);
+            aq[ks % 3] = *reinterpret_cast<const bf16x8*>(qs + ro);
+            ad[ks % 3] = *reinterpret_cast<const bf16x8*>(dos + ro);
+            kf[ks % 3] = *reinterpret_cast<const bf16x8*>(kimb + ro);
+          };
+          fetch(0);
+          fetch(1);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 naq = aq, nad = ad, nkf = kf;
-            if (ks + 1 < KS) {                                             // the next step's fragments are in flight under this step's MFMAs
-              const int ro = ro_of(ks + 1);
-              naq = *reinterpret_cast<const bf16x8*>(qs + ro); nad = *reinterpret_cast<const bf16x8*>(dos + ro);
-              nkf = *reinterpret_cast<const bf16x8*>(kimb + ro);
-            }
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[blk][ks], dp, 0, 0, 0);
-            aq = naq; ad = nad; kf = nkf;
+            if (ks + 2 < KS) fetch(ks + 2);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks % 3], kf[ks % 3], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[ks % 3], vf[blk][ks], dp, 0, 0, 0);
+            FENCE();
           }
         }
+        FENCE();
+        if (sl == 4 && blk == 0) stamp();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2_s + sl * QS + 8 * j + 4 * g);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sl * QS + 8 * j + 4 * g);
           u32x4 k4 = {0u, 0u, 0u, 0u};
           if constexpr (DROP) k4 = *reinterpret_cast<const u32x4*>(kw_s + 32 * blk + 8 * j + 4 * g);
+          dq_step(slq, 4 * blk + j);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int v = 4 * j + r;
@@ -361,7 +374,9 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
             s[v] = pd;
             dp[v] = DROP ? __builtin_fmaf(pd * dp[v], a.keep_scale, -t) : __builtin_fmaf(p, dp[v], -t);
           }
+          FENCE();
         }
+        if (sl == 4 && blk == 0) stamp();
 #pragma unroll
         for (int t = 0; t < 2; ++t) { pf[blk][t] = pack8(s, t); dsf[blk][t] = pack8(dp, t); }
         // key row 64 w + 32 blk + c, queries 8 j + 4 g .. + 3 = slot 2 j + g
@@ -373,6 +388,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
         }
         FENCE();
       }
+      if (sl > 0) dq_end(sl - 1);
       if (sl == 4) stamp();
       // ---- dV^T += dO^T.P, dK^T += Q^T.dS: A = transposed reads, rows 16 t + 4 g + q (+ 8), columns 32 db + 16 (G & 1) + 4 p
       {
@@ -399,7 +415,11 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
     }
     stamp();
     __syncthreads();
-    dq_slice(nslice - 1);
+    if (!first) dq_load_partial(nslice - 1);
+    dq_begin(nslice - 1);
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) { dq_step(nslice - 1, kk); FENCE(); }
+    dq_end(nslice - 1);
     __syncthreads();
     stamp();
     if (false) __syncthreads();                                                    // every wave is done with the K image: it becomes the store staging area
@@ -491,7 +511,8 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
   a.keep_scale = keep_scale(p.rate);
   const int tqp = (int)cdiv64(p.Tq, a2::QS) * a2::QS;
   const size_t smem = a2::Lds<96>::bytes(tqp);
-  auto kern = p.rate > 0.f ? a2::mha2_bwd_kernel<96, true> : a2::mha2_bwd_kernel<96, false>;
+  auto kern = a.stamps ? a2::mha2_bwd_kernel<96, true, true>
+                       : (p.rate > 0.f ? a2::mha2_bwd_kernel<96, true, false> : a2::mha2_bwd_kernel<96, false, false>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) { neurst_set_error("mha2_bwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
   kern<<<dim3((unsigned)(p.B * p.H)), 256, smem, s>>>(a);
