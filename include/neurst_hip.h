@@ -85,6 +85,18 @@ int neurst_gemm_wgrad_bias(const void* A, const void* B, float* C, float* opsum,
 int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const void* const* B, float* const* C, float* const* opsum,
                                    const int64_t* M, const int64_t* N, const int64_t* K, const int64_t* lda,
                                    const int64_t* ldb, const int64_t* ldc, int ab_dtype, void* stream);
+/* The grouped launch as a QUEUE of output tiles (same reference functions as above: the weight / bias gradients of
+ * `dense`, st/models/tools/utils.py:367-398): only tiles tile_begin[i] .. tile_end[i] - 1 of problem i are computed (a
+ * problem has neurst_gemm_wgrad_group_tiles(M_i, N_i) tiles of 256 x 192, independent of each other), so a caller can cut
+ * the tiles of many layers into launches of exactly 256 - one workgroup per CU - with a layer straddling two launches
+ * (st/models/graph.py).  Up to neurst_gemm_wgrad_group_max() problems.  When the tile kernel cannot take the operands
+ * (fp32 operands, alignment) a problem is computed whole by the call whose range starts at tile 0. */
+int neurst_gemm_wgrad_bias_grouped_tiles(int n, const void* const* A, const void* const* B, float* const* C,
+                                         float* const* opsum, const int64_t* M, const int64_t* N, const int64_t* K,
+                                         const int64_t* lda, const int64_t* ldb, const int64_t* ldc, const int* tile_begin,
+                                         const int* tile_end, int ab_dtype, void* stream);
+int64_t neurst_gemm_wgrad_group_tiles(int64_t M, int64_t N);
+int neurst_gemm_wgrad_group_max(void);
 /* column sums (bias gradients): out[n] (+)= sum_m x[m,n]; out fp32. */
 int neurst_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
                   void* stream);

@@ -639,23 +639,30 @@ extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const
 // Several weight (+ bias) gradients of `dense` layers in one launch (autodiff of st/models/tools/utils.py:367-398 for the
 // layers of one or two Transformer blocks): problem i is C_i[M_i,N_i] += A_i^T . B_i, A_i [K_i,M_i] = dY, B_i [K_i,N_i] = X,
 // opsum_i (may be NULL) += column sums of A_i.  bf16 operands, fp32 C.
-extern "C" int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const void* const* B, float* const* C, float* const* opsum,
-                                              const int64_t* M, const int64_t* N, const int64_t* K, const int64_t* lda, const int64_t* ldb,
-                                              const int64_t* ldc, int ab_dtype, void* stream) {
-  NEURST_CHECK_ARG(n >= 1 && n <= 8 && A && B && C && opsum && M && N && K && lda && ldb && ldc, "gemm_wgrad_bias_grouped: 1 to 8 problems");
-  GemmArgs gs[8];
+extern "C" int neurst_gemm_wgrad_bias_grouped_tiles(int n, const void* const* A, const void* const* B, float* const* C, float* const* opsum,
+                                                    const int64_t* M, const int64_t* N, const int64_t* K, const int64_t* lda, const int64_t* ldb,
+                                                    const int64_t* ldc, const int* tile_begin, const int* tile_end, int ab_dtype, void* stream) {
+  constexpr int MAXP = 12;
+  NEURST_CHECK_ARG(n >= 1 && n <= MAXP && n <= neurst_gemm256_group_max() && A && B && C && opsum && M && N && K && lda && ldb && ldc,
+                   "gemm_wgrad_bias_grouped: 1 to %d problems", MAXP);
+  NEURST_CHECK_ARG((tile_begin == nullptr) == (tile_end == nullptr), "gemm_wgrad_bias_grouped: tile_begin and tile_end go together");
+  GemmArgs gs[MAXP];
   for (int i = 0; i < n; ++i) {
     NEURST_CHECK_ARG(lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i], "gemm_wgrad_bias_grouped: leading dimension too small (problem %d)", i);
+    if (tile_begin)
+      NEURST_CHECK_ARG(tile_begin[i] >= 0 && tile_begin[i] <= tile_end[i] && tile_end[i] <= neurst_gemm256_group_tiles(M[i], N[i]),
+                       "gemm_wgrad_bias_grouped: tile range of problem %d outside 0..%lld", i, (long long)neurst_gemm256_group_tiles(M[i], N[i]));
     int rc = fill_gemm_args(gs[i], A[i], B[i], C[i], M[i], N[i], K[i], lda[i], ldb[i], ldc[i], ab_dtype, NEURST_F32);
     if (rc) return rc;
     gs[i].accumulate = 1; gs[i].split_k = 1; gs[i].opsum = opsum[i];
   }
   hipStream_t s = as_stream(stream);
-  if (ab_dtype == NEURST_BF16 && use_gemm256() && neurst_gemm256_group_launch(n, gs, s)) {
+  if (ab_dtype == NEURST_BF16 && use_gemm256() && neurst_gemm256_group_launch(n, gs, tile_begin, tile_end, s)) {
     NEURST_CHECK_LAUNCH("gemm256_group");
     return NEURST_OK;
   }
-  for (int i = 0; i < n; ++i) {                                // one launch per gradient (fp32 parity mode, odd shapes)
+  for (int i = 0; i < n; ++i) {                                // one launch per gradient (fp32 parity mode, odd shapes):
+    if (tile_begin && (tile_begin[i] != 0 || tile_end[i] == 0)) continue;   // whole, by the call that holds its first tile
     int rc;
     if (opsum[i]) rc = neurst_gemm_wgrad_bias(A[i], B[i], C[i], opsum[i], 1, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], ab_dtype, 1, stream);
     else rc = neurst_gemm_bias_act(A[i], B[i], C[i], nullptr, nullptr, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], 1, 0, ab_dtype, NEURST_F32, 0, 1, 1, stream);
@@ -663,6 +670,14 @@ extern "C" int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const
   }
   return NEURST_OK;
 }
+extern "C" int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const void* const* B, float* const* C, float* const* opsum,
+                                              const int64_t* M, const int64_t* N, const int64_t* K, const int64_t* lda, const int64_t* ldb,
+                                              const int64_t* ldc, int ab_dtype, void* stream) {
+  NEURST_CHECK_ARG(n >= 1 && n <= 8, "gemm_wgrad_bias_grouped: 1 to 8 problems");
+  return neurst_gemm_wgrad_bias_grouped_tiles(n, A, B, C, opsum, M, N, K, lda, ldb, ldc, nullptr, nullptr, ab_dtype, stream);
+}
+extern "C" int64_t neurst_gemm_wgrad_group_tiles(int64_t M, int64_t N) { return neurst_gemm256_group_tiles(M, N); }
+extern "C" int neurst_gemm_wgrad_group_max(void) { return neurst_gemm256_group_max(); }
 
 extern "C" int neurst_gemm_bias_act(const void* A, const void* B, void* C, const float* bias, const void* relu_src, int64_t M,
                                     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,

@@ -185,7 +185,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI],
 // NI1 = MFMA tiles (16 columns each) per wave in the SECOND B piece: 2 -> 256-column output tiles, 1 -> 192-column tiles
 // (wave tile 128 x 48; M = 16000 rows give 63 tile rows, so tile counts that are multiples of 4 per tile row fill 256 CUs
 // in whole rounds: N = 768 -> 252 tiles, 2304 -> 756, 1536 -> 504).
-template <typename TC, bool TA, bool TBK, int NI1, bool STAMPS, int ABL, bool SUMA>
+// ONE: the workgroup computes exactly one output tile, `block` = tile row | tile column << 16 (grouped weight gradients:
+// the launch's own placement rule decides which tile a workgroup gets); otherwise the persistent static schedule below.
+template <typename TC, bool TA, bool TBK, int NI1, bool STAMPS, int ABL, bool SUMA, bool ONE = false>
 __device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int block, const int G, unsigned long long* const stamps_buf) {
   constexpr bool AKS = TA, BKS = !TBK;                         // operand is k-strided in memory
   constexpr int NI = 2 + NI1, WN = 16 * NI, BNT = 4 * WN;      // MFMA tiles / columns per wave, columns per output tile
@@ -212,6 +214,7 @@ __device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int 
   const int rem_beg = full_rounds * G + (xcd < rr8 ? xcd * (rq + 1) : rr8 * (rq + 1) + (xcd - rr8) * rq);
   const int rem_cnt = xcd < rr8 ? rq + 1 : rq;
   auto tile_at = [&](int r) -> int {
+    if constexpr (ONE) return r == 0 ? block : -1;
     if (r < full_rounds) return r * G + xcd * per_xcd + loc;
     if (r == full_rounds && loc < rem_cnt) return rem_beg + loc;
     return -1;
@@ -219,6 +222,7 @@ __device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int 
   constexpr int GM = 8;
   const int per_group = GM * g.tiles_n;
   auto coords = [&](int t, int64_t& m0, int64_t& n0) {
+    if constexpr (ONE) { m0 = (int64_t)(t & 0xffff) * BM; n0 = (int64_t)(t >> 16) * BNT; return; }
     const int group = t / per_group, first_m = group * GM;
     const int gsz = g.tiles_m - first_m < GM ? g.tiles_m - first_m : GM;
     m0 = (int64_t)(first_m + (t % per_group) % gsz) * BM;
@@ -492,21 +496,35 @@ __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
 
 // Several weight gradients in ONE launch: C_i[M_i, N_i] += A_i^T . B_i with A_i [K_i][M_i] (dY), B_i [K_i][N_i] (X), fp32 C,
 // opsum_i (may be null) += column sums of A_i.  Every 256 x 192 tile of every problem is one workgroup that runs the whole
-// reduction (no split-K, no atomics on C): a single gradient has 12-48 tiles, a group is packed to fill the 256 CUs.
-constexpr int MAX_GROUP = 8;
+// reduction (no split-K, no atomics on C): a single gradient has 12-48 tiles, so the launch is a QUEUE of tiles - tiles
+// tile0[i] .. of problem i, problems in the order given - and the caller cuts that queue into launches of 256 tiles (a
+// gradient may straddle two launches: its tiles are independent).
+// Placement: the hardware deals workgroups to the 8 XCDs round-robin (blockIdx & 7), and each XCD has its own L2.  Queue
+// position q = (blockIdx & 7) * (grid / 8) + (blockIdx >> 3): every XCD takes a CONTIGUOUS run of the queue, and inside a
+// problem the queue walks the shorter tile dimension fastest, so the ~32 tiles of an XCD form a compact rectangle that shares
+// its operand panels in that L2 (8 x 4 tiles: 2.8 MB of operands per K-tile-row instead of 14 MB fetched tile by tile).
+constexpr int MAX_GROUP = 12;
 struct GroupArgs {
   GemmArgs gp[MAX_GROUP];
   int nk[MAX_GROUP];
-  int first[MAX_GROUP + 1];   // first workgroup of each problem
+  int first[MAX_GROUP + 1];   // queue position of each problem's first tile in this launch
+  int tile0[MAX_GROUP];       // index (in the problem's own tile order) of that tile
   int nprob;
 };
 __global__ void __launch_bounds__(NT, 2) gemm256_group_kernel(GroupArgs ga) {
+  const int per_xcd = (int)gridDim.x >> 3;
+  const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (q >= ga.first[ga.nprob]) return;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < MAX_GROUP; ++i)
-    if (i < ga.nprob && (int)blockIdx.x >= ga.first[i]) pi = i;
-  const int tiles = ga.first[pi + 1] - ga.first[pi];
-  body<float, true, false, 1, false, 0, true>(ga.gp[pi], ga.nk[pi], (int)blockIdx.x - ga.first[pi], (tiles + 7) & ~7, nullptr);
+    if (i < ga.nprob && q >= ga.first[i]) pi = i;
+  const GemmArgs& g = ga.gp[pi];
+  const int lt = q - ga.first[pi] + ga.tile0[pi];
+  int tm, tn;
+  if (g.tiles_m <= g.tiles_n) { tm = lt % g.tiles_m; tn = lt / g.tiles_m; }
+  else { tn = lt % g.tiles_n; tm = lt / g.tiles_n; }
+  body<float, true, false, 1, false, 0, true, true>(g, ga.nk[pi], tm | (tn << 16), 8, nullptr);
 }
 
 }  // namespace t2
@@ -597,9 +615,12 @@ void neurst_gemm256_launch(const GemmArgs& g, int trans_a, int trans_b, int c_dt
   else { if (wide) launch256<float, 2>(g, trans_a, trans_b, s); else launch256<float, 1>(g, trans_a, trans_b, s); }
 }
 
-// Grouped weight gradients (see t2::gemm256_group_kernel).  Host arrays of n <= 8 problems; returns false when a problem
-// does not fit the kernel (alignment, 32-bit window) - the caller then falls back to one launch per gradient.
-bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, hipStream_t s) {
+// Grouped weight gradients (see t2::gemm256_group_kernel).  Host arrays of n <= 12 problems; tiles tile_begin[i] ..
+// tile_end[i] - 1 of problem i (null: all of them).  Returns false when a problem does not fit the kernel (alignment, 32-bit
+// window) - the caller then falls back to one launch per gradient.
+int neurst_gemm256_group_max() { return t2::MAX_GROUP; }
+int64_t neurst_gemm256_group_tiles(int64_t M, int64_t N) { return cdiv64(M, t2::BM) * cdiv64(N, 192); }
+bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, const int* tile_begin, const int* tile_end, hipStream_t s) {
   if (n < 1 || n > t2::MAX_GROUP) return false;
   t2::GroupArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -611,13 +632,19 @@ bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, hipStream_t s) {
     ga.gp[i] = g;
     ga.gp[i].tiles_m = (int)cdiv64(g.M, t2::BM);
     ga.gp[i].tiles_n = (int)cdiv64(g.N, 192);
+    if (ga.gp[i].tiles_m > 0xffff || ga.gp[i].tiles_n > 0x7fff) return false;
     ga.gp[i].split_k = 1;
     ga.nk[i] = (int)((cdiv64(g.K, t2::BK) + 1) / 2 * 2);
+    const int all = ga.gp[i].tiles_m * ga.gp[i].tiles_n;
+    const int t0 = tile_begin ? tile_begin[i] : 0, t1 = tile_end ? tile_end[i] : all;
+    if (t0 < 0 || t1 > all || t0 > t1) return false;
     ga.first[i] = total;
-    total += ga.gp[i].tiles_m * ga.gp[i].tiles_n;
+    ga.tile0[i] = t0;
+    total += t1 - t0;
   }
   ga.first[n] = total;
   ga.nprob = n;
-  t2::gemm256_group_kernel<<<total, t2::NT, 0, s>>>(ga);
+  if (total == 0) return true;
+  t2::gemm256_group_kernel<<<(total + 7) / 8 * 8, t2::NT, 0, s>>>(ga);
   return true;
 }

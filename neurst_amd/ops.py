@@ -211,9 +211,10 @@ def gemm_wgrad_bias(A, B, C, opsum, sum_operand, M, N, K, lda, ldb, ldc, split_k
         _lib.check(rc, 'gemm_wgrad_bias')
 
 
-def gemm_wgrad_grouped(problems):
-    """[(A [K, M] = dY, B [K, N] = X, C [M, N] fp32, opsum [M] fp32 or None), ...] (at most 8): C += A^T . B and
-    opsum += column sums of A for every problem in one launch (neurst_gemm_wgrad_bias_grouped)."""
+def gemm_wgrad_grouped(problems, tile_ranges=None):
+    """[(A [K, M] = dY, B [K, N] = X, C [M, N] fp32, opsum [M] fp32 or None), ...] (at most wgrad_group_max()): C += A^T . B
+    and opsum += column sums of A for every problem in one launch (neurst_gemm_wgrad_bias_grouped_tiles).  tile_ranges
+    [(begin, end), ...]: only those 256 x 192 output tiles of each problem (wgrad_group_tiles(M, N) per problem)."""
     n = len(problems)
     P = ctypes.c_void_p * n
     L = ctypes.c_int64 * n
@@ -224,9 +225,22 @@ def gemm_wgrad_grouped(problems):
     M = L(*[a.shape[1] for a, _, _, _ in problems])
     N = L(*[b.shape[1] for _, b, _, _ in problems])
     K = L(*[a.shape[0] for a, _, _, _ in problems])
-    rc = _C.neurst_gemm_wgrad_bias_grouped(n, A, B, C, S, M, N, K, M, N, N, _DT[problems[0][0].dtype], _override_raw or _raw_stream(_cur_dev()))
+    T0 = T1 = None
+    if tile_ranges is not None:
+        I = ctypes.c_int * n
+        T0, T1 = I(*[r[0] for r in tile_ranges]), I(*[r[1] for r in tile_ranges])
+    rc = _C.neurst_gemm_wgrad_bias_grouped_tiles(n, A, B, C, S, M, N, K, M, N, N, T0, T1, _DT[problems[0][0].dtype],
+                                                 _override_raw or _raw_stream(_cur_dev()))
     if rc:
-        _lib.check(rc, 'gemm_wgrad_bias_grouped')
+        _lib.check(rc, 'gemm_wgrad_bias_grouped_tiles')
+
+
+def wgrad_group_tiles(M, N):
+    return int(_C.neurst_gemm_wgrad_group_tiles(M, N))
+
+
+def wgrad_group_max():
+    return int(_C.neurst_gemm_wgrad_group_max())
 
 
 def colsum(x2d, out, accumulate=True):

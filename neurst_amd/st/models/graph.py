@@ -225,6 +225,7 @@ class Graph:
         # NEURST_GROUP_WGRAD=0 turns it off (one split-K launch per gradient).
         self.group_wgrads = os.environ.get('NEURST_GROUP_WGRAD', '1') != '0'
         self.group_min_rows = 8192
+        self.group_launch_tiles = int(os.environ.get('NEURST_GROUP_TILES', '256'))
         self.pending_wgrads = []
         self.pending_tiles = 0
         self.pending_reads = set()
@@ -371,35 +372,53 @@ class Graph:
         tiles = -(-rows // 256) * -(-cols // 192)
         if tiles > 64 or rows % 8 or cols % 8:
             return False
-        if self.pending_wgrads and (self.pending_tiles + tiles > 256 or len(self.pending_wgrads) == 8):
-            self.flush_wgrads()
-        self.pending_wgrads.append((a, b, w, bias if layout == 'out_in' else None, bias))
+        # the pending gradients are a QUEUE of output tiles: whenever 256 are waiting, exactly 256 go out as one launch (one
+        # workgroup per CU), the last gradient of the launch possibly only in part - its other tiles lead the next launch
+        self.pending_wgrads.append([a, b, w, bias if layout == 'out_in' else None, bias, 0, tiles])
         self.pending_tiles += tiles
-        self.pending_reads.add(a.untyped_storage().data_ptr())
-        self.pending_reads.add(b.untyped_storage().data_ptr())
-        if self.pending_tiles >= 236:
-            self.flush_wgrads()
+        while self.pending_tiles >= self.group_launch_tiles:
+            self.launch_wgrad_tiles(self.group_launch_tiles)
+        self.pending_reads = {t.untyped_storage().data_ptr() for e in self.pending_wgrads for t in e[:2]}
         return True
 
-    def flush_wgrads(self):
-        """Launch the pending group (on the weight-gradient stream when there is one) and report its parameters done."""
-        group, self.pending_wgrads, self.pending_tiles = self.pending_wgrads, [], 0
-        self.pending_reads.clear()
-        if not group:
+    def launch_wgrad_tiles(self, budget):
+        """One grouped launch of up to `budget` tiles from the head of the queue (on the weight-gradient stream when there
+        is one); gradients whose last tile went out are reported done."""
+        probs, ranges, done = [], [], []
+        nmax = ops.wgrad_group_max()
+        while self.pending_wgrads and budget > 0 and len(probs) < nmax:
+            e = self.pending_wgrads[0]
+            a, b, w, bs, bias, t0, tiles = e
+            take = min(tiles - t0, budget)
+            probs.append((a, b, w.grad, (bs.grad if bs is not None else None)))
+            ranges.append((t0, t0 + take))
+            budget -= take
+            self.pending_tiles -= take
+            e[5] = t0 + take
+            if e[5] == tiles:
+                self.pending_wgrads.pop(0)
+                done.append((w, bias))
+        if not probs:
             return
-        K = group[0][0].shape[0]
-        side = self.side_stream_for(K, group[0][0].device)
+        K = probs[0][0].shape[0]
+        side = self.side_stream_for(K, probs[0][0].device)
 
         def launch():
-            ops.gemm_wgrad_grouped([(a, b, w.grad, (bs.grad if bs is not None else None)) for a, b, w, bs, _ in group])
+            ops.gemm_wgrad_grouped(probs, ranges)
         if side is not None:
-            self.run_on_side(side, launch, *[t for a, b, _, _, _ in group for t in (a, b)])
+            self.run_on_side(side, launch, *[t for a, b, _, _ in probs for t in (a, b)])
         else:
             launch()
-        for _, _, w, _, bias in group:
+        for w, bias in done:
             self.param_grad_done(w)
             if bias is not None:
                 self.param_grad_done(bias)
+
+    def flush_wgrads(self):
+        """Launch everything that is pending."""
+        while self.pending_wgrads:
+            self.launch_wgrad_tiles(self.group_launch_tiles)
+        self.pending_reads = set()
 
     def before_inplace_write(self, t):
         """Main-stream kernels are about to update `t` in place: if a side-stream kernel may still read that storage,

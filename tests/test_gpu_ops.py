@@ -262,6 +262,45 @@ def test_grouped_weight_gradients(shapes):
     assert relerr(host(C1), refs[0][0]) < 1e-5 and relerr(host(s1), refs[0][1]) < 1e-5
 
 
+def test_grouped_weight_gradients_as_a_tile_queue():
+    """neurst_gemm_wgrad_bias_grouped_tiles: the tiles of several gradients cut into launches at arbitrary queue positions
+    (a gradient straddling two or three launches) give bit-identical dW / db to ONE launch of everything - every 256 x 192
+    tile is the same whole-K sum wherever it runs - and an empty or out-of-range tile range is handled / rejected."""
+    rng = np.random.default_rng(11)
+    shapes = [(2304, 768), (768, 768), (776, 520), (768, 3072), (264, 200)]
+    K = 1000
+    ops_in = [(dev(bf16_round(rng.standard_normal((K, M)) * 0.1), torch.bfloat16), dev(bf16_round(rng.standard_normal((K, N)) * 0.1), torch.bfloat16))
+              for M, N in shapes]
+
+    def fresh():
+        return [(a, b, torch.ones((a.shape[1], b.shape[1]), dtype=torch.float32, device=DEV),
+                 (torch.full((a.shape[1],), 2.0, dtype=torch.float32, device=DEV) if i != 1 else None)) for i, (a, b) in enumerate(ops_in)]
+    tiles = [ops.wgrad_group_tiles(M, N) for M, N in shapes]
+    assert tiles == [36, 12, 12, 48, 4] and ops.wgrad_group_max() >= 8
+    whole = fresh()
+    ops.gemm_wgrad_grouped(whole)
+    for cut in (5, 17, 50):                                    # launches of `cut` tiles from the head of the queue
+        probs = fresh()
+        nxt = [0] * len(probs)
+        while any(n < t for n, t in zip(nxt, tiles)):
+            budget, sel, rng_ = cut, [], []
+            for i, t in enumerate(tiles):
+                if nxt[i] < t and budget > 0:
+                    take = min(t - nxt[i], budget)
+                    sel.append(probs[i]); rng_.append((nxt[i], nxt[i] + take))
+                    nxt[i] += take; budget -= take
+            ops.gemm_wgrad_grouped(sel, rng_)
+        for (_, _, C, s), (_, _, C0, s0) in zip(probs, whole):
+            assert torch.equal(C, C0)
+            if s is not None:
+                assert relerr(host(s), host(s0)) < 1e-6          # atomics: order of the adds differs
+    probs = fresh()
+    ops.gemm_wgrad_grouped(probs[:1], [(3, 3)])                  # empty range: nothing happens
+    assert torch.equal(probs[0][2], torch.ones_like(probs[0][2]))
+    with pytest.raises(Exception):
+        ops.gemm_wgrad_grouped(probs[:1], [(0, 37)])
+
+
 def test_set_option_rejects_unknown_names():
     from neurst_amd import lib
     C = lib.load()
