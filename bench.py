@@ -110,15 +110,24 @@ class KernelTimer:
         ops.gemm_wgrad_bias = gemm_wgrad_bias
         orig_g = ops.gemm_wgrad_grouped
 
-        def gemm_wgrad_grouped(problems):
+        def gemm_wgrad_grouped(problems, tile_ranges=None):
             if not timer.enabled:
-                return orig_g(problems)
+                return orig_g(problems, tile_ranges)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             st = ops.active_stream()
             e0.record(st)
-            r = orig_g(problems)
+            r = orig_g(problems, tile_ranges)
             e1.record(st)
-            fl = sum(2.0 * a_.shape[1] * b_.shape[1] * a_.shape[0] for a_, b_, _, _ in problems)
+            if tile_ranges is None:
+                fl = sum(2.0 * a_.shape[1] * b_.shape[1] * a_.shape[0] for a_, b_, _, _ in problems)
+            else:                                          # the launch's 256 x 192 tiles, edge tiles at their true size
+                fl = 0.0
+                for (a_, b_, _, _), (t0, t1) in zip(problems, tile_ranges):
+                    Mm, Nn = a_.shape[1], b_.shape[1]
+                    tm_n, tn_n = -(-Mm // 256), -(-Nn // 192)
+                    for lt in range(t0, t1):               # the kernel's order: the shorter tile dimension runs fastest
+                        tm, tn = (lt % tm_n, lt // tm_n) if tm_n <= tn_n else (lt // tn_n, lt % tn_n)
+                        fl += 2.0 * min(256, Mm - 256 * tm) * min(192, Nn - 192 * tn) * a_.shape[0]
             timer.records.setdefault('gemm256_group_kernel', []).append((e0, e1, fl))
             return r
         ops.gemm_wgrad_grouped = gemm_wgrad_grouped

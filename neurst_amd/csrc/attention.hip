@@ -168,7 +168,7 @@ struct AttnArgs {
   int64_t B, H, Tq, Tk;
   int dh, mask_mode;
   const int32_t* len_k;
-  uint32_t thr, key, inner0;   // inner0 = fmix32(key): the inner hash when every flat index fits 32 bits
+  uint32_t thr, key, inner0;   // thr: 16-bit keep threshold (0 = no dropout); inner0 = fmix32(key): the inner hash when every counter fits 32 bits
   int idx32;
   float keep_scale, qscale;
   int q_aligned, k_aligned, v_aligned, o_aligned;
@@ -192,30 +192,18 @@ __device__ __forceinline__ BlockId remap_block() {
   return BlockId{id % nx, (id / nx) % ny, id / (nx * ny)};
 }
 
-// dropout decision for weight (row, col): row_base = flat index of the row's first weight
-__device__ __forceinline__ bool attn_keep(const AttnArgs& a, uint64_t row_base, int col) {
-  if (a.idx32) return (fmix32(((uint32_t)row_base + (uint32_t)col) ^ a.inner0) >> 8) >= a.thr;
-  return dropout_keep(a.key, row_base + (uint64_t)col, a.thr);
+// The two keep words (keys kv0 .. kv0 + 63) of attention row `row` (= (b*H + h)*Tq + q), generated here: lanes l, l^16, l^32,
+// l^48 share a row - the even 16-lane groups draw the first word, the odd ones the second, one shuffle exchanges them.
+__device__ __forceinline__ void gen_tile_words(const AttnArgs& a, int lane, int64_t row, int64_t kv0, uint32_t& w0, uint32_t& w1) {
+  const int odd = (lane >> 4) & 1;
+  uint32_t mine = attn_keep_word(a.key, a.inner0, a.idx32, (uint64_t)(row * a.nw + (kv0 >> 5) + odd), a.thr);
+  asm volatile("" : "+v"(mine));                              // keeps the generator out of the MFMA phases' schedule
+  const uint32_t other = __shfl_xor(mine, 16, 64);
+  w0 = odd ? other : mine;
+  w1 = odd ? mine : other;
 }
-
-// keep decisions of the 16 weights a lane owns in one 64-wide tile, as a bit mask (bit nt*4 + r <-> flat index
-// base + col0 + nt*stride_nt + r*stride_r).  Kept behind an opaque barrier so that the hash arithmetic is not
-// interleaved with (and does not hold registers across) the MFMA phases.
-__device__ __forceinline__ uint32_t keep_bits16(const AttnArgs& a, uint64_t base, int col0, int stride_nt, int stride_r) {
-  uint32_t m = 0xFFFFu;
-  if (a.thr) {
-    m = 0;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m |= (attn_keep(a, base, col0 + nt * stride_nt + r * stride_r) ? 1u : 0u) << (nt * 4 + r);
-  }
-  asm volatile("" : "+v"(m));
-  return m;
-}
-
-// The 16 decisions of keep_bits16(base, col0 = kv0 + 4g, 16, 1) (bit nt*4 + r <-> key kv0 + 16 nt + 4 g + r) <-> the two bitmap
-// words of the 64-key tile: word (nt >> 1), bits 16 (nt & 1) + 4 g + r.
+// The 16 decisions a lane of 16-lane group g owns in a 64-key tile (bit nt*4 + r <-> key kv0 + 16 nt + 4 g + r) <-> the two bitmap
+// words of the tile: word (nt >> 1), bits 16 (nt & 1) + 4 g + r.
 __device__ __forceinline__ void kmask_to_words(uint32_t kmask, int g, uint32_t& w0, uint32_t& w1) {
   w0 = ((kmask & 0xFu) << (4 * g)) | (((kmask >> 4) & 0xFu) << (16 + 4 * g));
   w1 = (((kmask >> 8) & 0xFu) << (4 * g)) | (((kmask >> 12) & 0xFu) << (16 + 4 * g));
@@ -223,17 +211,21 @@ __device__ __forceinline__ void kmask_to_words(uint32_t kmask, int g, uint32_t& 
 __device__ __forceinline__ uint32_t words_to_kmask(uint32_t w0, uint32_t w1, int g) {
   return ((w0 >> (4 * g)) & 0xFu) | (((w0 >> (16 + 4 * g)) & 0xFu) << 4) | (((w1 >> (4 * g)) & 0xFu) << 8) | (((w1 >> (16 + 4 * g)) & 0xFu) << 12);
 }
-// lanes l, l^16, l^32, l^48 hold the four nibble groups of one query's words: OR them and let the g == 0 lane store
-__device__ __forceinline__ void store_keep_words(const AttnArgs& a, uint32_t kmask, int lane, int64_t row, bool row_ok, int64_t kv0) {
-  uint32_t w0, w1;
-  kmask_to_words(kmask, lane >> 4, w0, w1);
-  w0 |= __shfl_xor(w0, 16, 64); w1 |= __shfl_xor(w1, 16, 64);
-  w0 |= __shfl_xor(w0, 32, 64); w1 |= __shfl_xor(w1, 32, 64);
+// every lane of a row holds both words: the g == 0 lane stores them
+__device__ __forceinline__ void store_tile_words(const AttnArgs& a, uint32_t w0, uint32_t w1, int lane, int64_t row, bool row_ok, int64_t kv0) {
   if (lane < 16 && row_ok) {
     uint32_t* p = a.keep_bits + row * a.nw + (kv0 >> 5);
     p[0] = w0;
     if ((kv0 >> 5) + 1 < a.nw) p[1] = w1;
   }
+}
+// this lane's 16 decisions of the tile, generated (and stored when there is a bitmap to fill) or all-ones without dropout
+__device__ __forceinline__ uint32_t gen_kmask(const AttnArgs& a, int lane, int64_t row, bool row_ok, int64_t kv0, bool store) {
+  if (!a.thr) return 0xFFFFu;
+  uint32_t w0, w1;
+  gen_tile_words(a, lane, row, kv0, w0, w1);
+  if (store) store_tile_words(a, w0, w1, lane, row, row_ok, kv0);
+  return words_to_kmask(w0, w1, lane >> 4);
 }
 __device__ __forceinline__ uint32_t load_keep_words(const AttnArgs& a, int lane, int64_t row, bool row_ok, int64_t kv0) {
   if (!row_ok) return 0u;
@@ -300,7 +292,6 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
   for (int i = 0; i < DH / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   const int64_t bh = b * a.H + h, qi = q0 + w * 16 + (lane & 15);
-  const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
 
   TileRegs<T, DH, FULL> kreg, vreg;
   kreg.load(kg, a.ldk, 0, a.Tk, dh, a.k_aligned, tid);
@@ -347,8 +338,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
     if (a.keep_bits_ready) {
       kmask = load_keep_words(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0);
     } else {
-      kmask = keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
-      if (a.keep_bits && a.thr) store_keep_words(a, kmask, lane, bh * a.Tq + qi, qi < a.Tq, kv0);
+      kmask = gen_kmask(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0, a.keep_bits != nullptr);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -428,7 +418,6 @@ __global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArg
     if (lane < 16 && qi < a.Tq) a.delta[bh * a.Tq + qi] = del;
   }
   const float lse_q = (qi < a.Tq ? a.lse_in[bh * a.Tq + qi] : 0.f) * unit;
-  const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
   f32x4 dqacc[DH / 16];
 #pragma unroll
   for (int i = 0; i < DH / 16; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -447,7 +436,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArg
     }
     const bool edge = a.mask_mode == NEURST_MASK_CAUSAL || kv0 + 64 > kv_lim || q_tail;
     const uint32_t kmask = (a.keep_bits && a.thr) ? load_keep_words(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0)
-                                                  : keep_bits16(a, rowb, (int)kv0 + g4, 16, 1);
+                                                  : gen_kmask(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0, false);
     f32x4 ds[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -527,14 +516,17 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
   TileRegs<T, DH, FULL> qreg, doreg;
   float lse_reg = 0.f, del_reg = 0.f;   // threads 0..63: statistics of query q0 + tid of the staged tile
   uint32_t mask_reg = 0;                // threads 64..191: bitmap word (tid - 64) >> 6 of query (tid - 64) & 63
-  const bool stored = a.keep_bits && a.thr;
+  const bool stored = a.thr != 0;       // dropout: the words come from the bitmap, or are drawn again here when there is none
   auto load_stats = [&](int64_t q0n) {
     const int64_t qi = q0n + tid;
     if (tid < 64 && qi < a.Tq) { lse_reg = a.lse_in[bh * a.Tq + qi] * unit; del_reg = a.delta[bh * a.Tq + qi]; }
     else { lse_reg = 0.f; del_reg = 0.f; }
     if (stored && tid >= 64 && tid < 192) {
       const int64_t qm = q0n + ((tid - 64) & 63), wi = (kv0 >> 5) + ((tid - 64) >> 6);
-      mask_reg = (qm < a.Tq && wi < a.nw) ? a.keep_bits[(bh * a.Tq + qm) * a.nw + wi] : 0u;
+      if (qm < a.Tq && wi < a.nw)
+        mask_reg = a.keep_bits ? a.keep_bits[(bh * a.Tq + qm) * a.nw + wi]
+                               : attn_keep_word(a.key, a.inner0, a.idx32, (uint64_t)((bh * a.Tq + qm) * a.nw + wi), a.thr);
+      else mask_reg = 0u;
     }
   };
   if (q_begin < a.Tq) {
@@ -577,7 +569,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnA
         for (int r = 0; r < 4; ++r) kmask |= ((m4[r] >> sh) & 1u) << (nt * 4 + r);
       }
     } else {
-      kmask = keep_bits16(a, (uint64_t)((bh * a.Tq + q0) * a.Tk) + (uint64_t)kj, g4 * (int)a.Tk, 16 * (int)a.Tk, (int)a.Tk);
+      kmask = 0xFFFFu;
     }
     // two halves of 32 queries: the probabilities of a half are consumed by the second products right away
 #pragma unroll 1
@@ -667,11 +659,11 @@ static int fill_args(AttnArgs& a, int64_t B, int64_t H, int64_t Tq, int64_t Tk, 
   if (!a.bsv) a.bsv = Tk * a.ldv;
   if (!a.bso) a.bso = Tq * a.ldo;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.dh = (int)dh; a.mask_mode = mask_mode; a.len_k = len_k;
-  a.thr = rate > 0.f ? rate_threshold(rate) : 0u;
+  a.thr = rate > 0.f ? attn_threshold16(rate) : 0u;   // keep iff the 16-bit draw is below it (common.h:attn_keep_word); 0 = no dropout
   a.key = key; a.keep_scale = keep_scale(rate);
   a.nw = (int)cdiv64(Tk, 32);
   a.inner0 = fmix32(key);   // == fmix32(hi ^ key) with hi == 0
-  a.idx32 = (double)B * (double)H * (double)Tq * (double)Tk < 4294967296.0;
+  a.idx32 = (double)B * (double)H * (double)Tq * (double)a.nw * 4.0 < 4294967296.0;   // counters 4 widx + j of every keep word
   a.qscale = 1.0f / sqrtf((float)dh);
   size_t es = dtype_size(dtype);
   auto al = [&](const void* p, int64_t ld) { return (int)((((uintptr_t)p & 15) == 0) && ((ld * es) % 16 == 0) && ((dh * es) % 16 == 0)); };
@@ -702,9 +694,8 @@ __global__ void __launch_bounds__(256) mha_keep_bits_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
   const BlockId bid = remap_block();
   const int64_t bh = bid.z * a.H + bid.y, qi = bid.x * 64 + w * 16 + (lane & 15);
-  const uint64_t rowb = (uint64_t)((bh * a.Tq + qi) * a.Tk);
   for (int64_t kv0 = 0; kv0 < a.Tk; kv0 += 64)
-    store_keep_words(a, keep_bits16(a, rowb, (int)kv0 + g4, 16, 1), lane, bh * a.Tq + qi, qi < a.Tq, kv0);
+    gen_kmask(a, lane, bh * a.Tq + qi, qi < a.Tq, kv0, true);
 }
 
 extern "C" int neurst_mha_keep_bits(uint16_t* keep_bits, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float rate, uint32_t key, void* stream) {

@@ -64,6 +64,47 @@ __device__ __forceinline__ bool dropout_keep(uint32_t key, uint64_t idx, uint32_
   return (h >> 8) >= thr;
 }
 static inline uint32_t rate_threshold(float rate) { return (uint32_t)(rate * 16777216.0f); }
+// ---- attention-weight dropout: 32 decisions per word (oracle/ops.py:attn_keep_words - the rule is stated there) ----------
+// widx = row * nw + w; W[k] = xorshift32^(k >> 2)(fmix32-hash of counter 4 widx + (k & 3)); bit i of the result = keep
+// decision of key 32 w + i: the 16-bit number with digits NOT bit_i(W[k]) is below t16 = round((1 - rate) * 65536).
+// inner0 = fmix32(key), idx32 = every counter fits 32 bits.  ~165 vector instructions per word (5 per decision; the
+// per-weight hash it replaces: 19, two of them quarter-rate multiplies).
+__host__ __device__ __forceinline__ uint32_t xorshift32(uint32_t x) {
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return x;
+}
+static inline uint32_t attn_threshold16(float rate) {
+  int t = (int)floor((1.0 - (double)rate) * 65536.0 + 0.5);
+  return (uint32_t)(t < 1 ? 1 : (t > 65535 ? 65535 : t));
+}
+__device__ __forceinline__ uint32_t attn_keep_word(uint32_t key, uint32_t inner0, int idx32, uint64_t widx, uint32_t t16) {
+  uint32_t c[4];
+  if (idx32) {
+    const uint32_t base = (uint32_t)widx * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = fmix32((base + j) ^ inner0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t ctr = widx * 4u + j;
+      c[j] = fmix32((uint32_t)ctr ^ fmix32((uint32_t)(ctr >> 32) ^ key));
+    }
+  }
+  uint32_t lt = 0u;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k && (k & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = xorshift32(c[j]);
+    }
+    const uint32_t W = c[k & 3], m = 0u - ((t16 >> k) & 1u);     // m: wave-uniform all-ones / zero
+    const uint32_t x = lt ^ W;
+    lt = (x & m) | (~x & lt);                                     // bit k of t16 set: lt | W, clear: lt & W
+  }
+  return lt;
+}
 static inline float keep_scale(float rate) { return 1.0f / (1.0f - rate); }
 
 // ---- wave / block reductions ---------------------------------------------------

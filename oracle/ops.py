@@ -49,6 +49,54 @@ def keep_mask(key, n, rate):
     return (h >> np.uint64(8)) >= np.uint64(rate_threshold(rate))
 
 
+# Attention-weight dropout draws its decisions 32 at a time - one 32-bit word per (attention row, 32 consecutive keys), the
+# unit the kernels store and exchange (keep bitmap [B*H][Tq][ceil(Tk/32)]) - instead of one 32-bit hash per weight, which
+# was 15-20 % of the attention forward.  Word number widx = row * nw + w draws sixteen random words
+#     W[k] = xorshift32^(k >> 2)( fmix32(lo(4 widx + (k & 3)) ^ fmix32(hi(4 widx + (k & 3)) ^ key)) ),  k = 0..15
+# (four hashed seeds, each followed by its three xorshift32 successors); key 32 w + i of the row owns bit i of every word:
+# the 16-bit number U_i with binary digits NOT bit_i(W[k]) (k = 15 most significant) is uniform, and the weight is KEPT iff
+# U_i < t16 = round((1 - rate) * 65536), evaluated for all 32 keys at once, digit by digit from the least significant:
+#     lt = 0;  for k = 0..15:  lt = (lt | W[k]) if bit k of t16 else (lt & W[k])
+# P(keep) = t16 / 65536 (0.899994 for rate 0.1; kept weights are still scaled by 1 / (1 - rate) as tf.nn.dropout does).
+def attn_threshold16(rate):
+    t = int(np.floor((1.0 - float(np.float32(rate))) * 65536.0 + 0.5))
+    return min(max(t, 1), 65535)
+
+
+def xorshift32(x):
+    x = np.asarray(x, dtype=np.uint64) & _M32
+    x ^= (x << np.uint64(13)) & _M32
+    x ^= x >> np.uint64(17)
+    x ^= (x << np.uint64(5)) & _M32
+    return x
+
+
+def attn_keep_words(key, n_rows, nw, rate):
+    """uint32 [n_rows, nw]: bit i of word w of a row = keep decision of key 32 w + i (the kernels' keep bitmap)."""
+    widx = np.arange(int(n_rows) * int(nw), dtype=np.uint64)
+    t16 = attn_threshold16(rate)
+    seeds = []
+    for j in range(4):
+        ctr = widx * np.uint64(4) + np.uint64(j)
+        seeds.append(fmix32((ctr & _M32) ^ fmix32((ctr >> np.uint64(32)) ^ np.uint64(key))))
+    lt = np.zeros_like(widx)
+    chain = list(seeds)
+    for k in range(16):
+        if k and (k & 3) == 0:
+            chain = [xorshift32(c) for c in chain]
+        W = chain[k & 3]
+        lt = (lt | W) if (t16 >> k) & 1 else (lt & W)
+    return lt.astype(np.uint32).reshape(int(n_rows), int(nw))
+
+
+def attn_keep_mask(key, n_rows, Tk, rate):
+    """bool [n_rows, Tk] from attn_keep_words."""
+    nw = (int(Tk) + 31) // 32
+    words = attn_keep_words(key, n_rows, nw, rate)
+    bits = (words[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & np.uint32(1)
+    return bits.reshape(int(n_rows), nw * 32)[:, :int(Tk)].astype(bool)
+
+
 def dropout_fwd(x, rate, key=None, mask=None):
     """tf.nn.dropout(x, keep_prob=1-rate): kept elements scaled by 1/(1-rate).
     Returns (y, m) with m the multiplicative mask (already scaled)."""
@@ -276,6 +324,9 @@ def mha_core_fwd(q, k, v, H, mask_mode, len_k=None, rate=0.0, key=None, drop_mas
     logits = logits - logits.max(-1, keepdims=True)
     e = np.exp(logits)
     w = e / e.sum(-1, keepdims=True)
+    if drop_mask is None and rate != 0.0:            # tf.nn.dropout on the weights (common_attention_v1.py:357-359), word rule above
+        keep = attn_keep_mask(key, B * H * Tq, Tk, rate).reshape(w.shape)
+        drop_mask = keep.astype(w.dtype) * dt(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
     wd, m = dropout_fwd(w, rate, key, drop_mask)
     out = combine_heads(wd @ vh)
     return out, (qh, kh, vh, w, wd, m, H)

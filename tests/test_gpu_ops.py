@@ -760,6 +760,10 @@ def test_attention_forward_with_decisions_generated_ahead(B, H, Tq, Tk, dh, mode
     kb = ops.mha_keep_bits(B, H, Tq, Tk, 0.1, 4242, DEV)
     o2, lse2, kb2 = ops.mha_fwd(q.view(-1), kf, kf[d:], d, 2 * d, 2 * d, B, H, Tq, Tk, dh, mm, ln, 0.1, 4242, keep_bits=kb)
     assert kb2 is kb and torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    # the generator kernel against the oracle's statement of the rule: every word, bit for bit
+    nw = (Tk + 31) // 32
+    want = O.attn_keep_words(4242, B * H * Tq, nw, 0.1)
+    assert np.array_equal(kb.cpu().numpy().view(np.uint32).reshape(B * H * Tq, nw), want)
     if mode == 'keypad':        # with full lengths the forward visits (and stores) every tile: the buffers agree entirely
         o3, _, kb3 = ops.mha_fwd(q.view(-1), kf, kf[d:], d, 2 * d, 2 * d, B, H, Tq, Tk, dh, ops.MASK_NONE, None, 0.1, 4242, keep_bits=True)
         assert torch.equal(kb3, kb)

@@ -118,6 +118,41 @@ def test_dropout_masks_are_reproducible_and_unbiased():
     assert ops.keep_mask(ops.site_key(5, 103, 7), 1000, 0.1).tolist() != m1[:1000].tolist()
 
 
+def test_attention_keep_words_follow_their_stated_rule():
+    """attn_keep_words (32 decisions per word, bit-sliced 16-bit comparison) against a scalar restatement of the rule in its
+    comment, and its statistics: P(keep) = t16 / 65536, decisions inside a word uncorrelated, drops per word binomial."""
+    key, rate, nw = ops.site_key(3, 41, 9), 0.1, 3
+    words = ops.attn_keep_words(key, 5, nw, rate)
+    t16 = ops.attn_threshold16(rate)
+    assert t16 == 58982 and ops.attn_threshold16(0.5) == 32768
+
+    def fm(x):
+        x &= 0xFFFFFFFF; x ^= x >> 16; x = (x * 0x85EBCA6B) & 0xFFFFFFFF; x ^= x >> 13; x = (x * 0xC2B2AE35) & 0xFFFFFFFF; x ^= x >> 16
+        return x
+
+    def xs(x):
+        x ^= (x << 13) & 0xFFFFFFFF; x ^= x >> 17; x ^= (x << 5) & 0xFFFFFFFF
+        return x
+    for widx in (0, 7, 14):
+        W = []
+        for k in range(16):
+            v = fm((4 * widx + (k & 3)) ^ fm(0 ^ key))
+            for _ in range(k >> 2):
+                v = xs(v)
+            W.append(v)
+        for i in range(32):
+            U = sum((1 - ((W[k] >> i) & 1)) << k for k in range(16))
+            assert bool((int(words.reshape(-1)[widx]) >> i) & 1) == (U < t16)
+    m = ops.attn_keep_mask(key, 100000, 64, rate).astype(np.float64)
+    assert m.shape == (100000, 64) and abs(m.mean() - t16 / 65536.0) < 1e-3
+    c = np.corrcoef(m.T)
+    np.fill_diagonal(c, 0)
+    assert np.abs(c).max() < 0.02
+    drops = (1 - m[:, :32]).sum(1)
+    assert abs(drops.var() - 32 * 0.1 * 0.9) < 0.1
+    assert not np.array_equal(ops.attn_keep_words(key + 1, 5, nw, rate), words)
+
+
 def test_greedy_infer_runs_and_matches_teacher_forcing_prefix():
     cfg = tiny_cfg(max_len=12)
     P = init_params(cfg, seed=4, dtype=np.float64, perturb=True)
