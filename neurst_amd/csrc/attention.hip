@@ -737,6 +737,11 @@ static int mha_fwd_impl(const void* q, const void* k, const void* v, void* o, fl
   if ((a.bsk * es) % 16) a.k_aligned = 0;
   if ((a.bsv * es) % 16) a.v_aligned = 0;
   hipStream_t s = as_stream(stream);
+  {
+    Mha2FwdProblem p = {q, k, v, o, lse, a.keep_bits, keep_bits_ready, ldq, ldk, ldv, ldo, a.bsq, a.bsk, a.bsv, a.bso, B, H, Tq, Tk, dh,
+                        mask_mode, len_k, rate, key, dtype};
+    if (neurst_mha2_fwd_eligible(p)) return neurst_mha2_fwd_launch(p, s);
+  }
   dim3 grid((unsigned)cdiv64(Tq, 64), (unsigned)H, (unsigned)B);
   if (dtype == NEURST_BF16) DISPATCH_DH(bf16_t, mha_fwd_kernel, fwd_smem, grid, "mha_fwd");
   else DISPATCH_DH(float, mha_fwd_kernel, fwd_smem, grid, "mha_fwd");

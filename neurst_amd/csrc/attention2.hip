@@ -463,12 +463,274 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward for the same shapes (bf16, dh = 96, no causal mask), "query on the lane":
+//   S^T = K.Q^T   v_mfma_f32_32x32x16_bf16: A = rows of a 32-key tile of the K image (LDS, b128), B = this wave's 32 queries,
+//                 held in registers for the whole sweep.  A lane owns ONE query (column c) and 16 of the tile's 32 keys:
+//                 running maximum and sum are per-lane scalars, one exchange between the two 32-lane halves per tile.
+//   P^T -> bf16   the accumulator tile is already the B operand of the second product (keys in the permuted k order
+//                 16 t + 8 (i >> 2) + 4 g + (i & 3), as in the backward above)
+//   O^T += V^T.P^T   A = transposed reads (ds_read_b64_tr_b16) of the V image; the rescale by exp2(m_old - m_new) is a
+//                 per-lane factor on the accumulator columns and is skipped while no lane's maximum moved.
+// One workgroup = 8 waves (two per SIMD: one wave's vector work - exp2, dropout words - runs under the other's MFMAs) = one
+// (batch, head); a wave sweeps all keys for one 32-query slice, then takes slice + 8.  K / V arrive in blocks of 128 keys by
+// LDS-DMA, double-buffered, one barrier per block.  Dropout decisions are drawn 32 at a time (common.h:attn_keep_word): the
+// two halves of a wave draw the words of two consecutive key tiles and swap them (v_permlane32_swap); every drawn word is
+// also the bitmap word the backward reads.
+// x of the lower 32 lanes -> lo (in every lane), x of the upper 32 lanes -> hi: v_permlane32_swap swaps lanes 32..63 of its
+// first operand with lanes 0..31 of its second.  The second operand is made opaque: given the same value twice the
+// compiler folds the two results into one (observed: "v_add v2, v139, v139" for sw[0] + sw[1]).
+__device__ __forceinline__ void halves(unsigned x, unsigned& lo, unsigned& hi) {
+  unsigned y = x;
+  asm volatile("" : "+v"(y));
+  const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  lo = sw[0];
+  hi = sw[1];
+}
+__device__ __forceinline__ void halves(float x, float& lo, float& hi) {
+  unsigned a, b;
+  halves(__builtin_bit_cast(unsigned, x), a, b);
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+constexpr int KBF = 128;       // keys per block
+constexpr int FW = 8;          // waves
+template <int DH> struct LdsF {
+  static constexpr int IMG_B = KBF * ROWB;
+  static constexpr int K0 = 0, V0 = 2 * IMG_B;              // [2 buffers] each
+  static constexpr int OST0 = 4 * IMG_B, OST_B = QS * ROWB;  // per-wave output staging tile
+  static constexpr int BYTES = OST0 + FW * OST_B;
+};
+struct FwdArgs {
+  const bf16_t *q, *k, *v;
+  bf16_t* o;
+  float* lse;
+  uint32_t* keep;            // bitmap to fill (rate > 0), or null
+  int keep_ready;            // the bitmap already holds the decisions (neurst_mha_keep_bits): load instead of drawing
+  const int32_t* len_k;
+  int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
+  int B, H, Tq, Tk, nw, keypad, idx32;
+  uint32_t key, inner0, t16;
+  float qscale, keep_scale;
+};
+
+template <int DH, bool DROP, int ABL = 0>
+__global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
+  typedef LdsF<DH> L;
+  constexpr int KS = DH / 16, DB = DH / 32, CH = DH / 8;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, g = lane >> 5;
+  const int G = lane >> 4, qq = (lane & 15) >> 2, p4 = lane & 3;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int Tq = a.Tq, Tk = a.Tk;
+  typedef __attribute__((address_space(3))) char* lds_cp;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_cp)smem;
+  const bf16_t* qg = a.q + (int64_t)b * a.bsq + h * DH;
+  const bf16_t* kg = a.k + (int64_t)b * a.bsk + h * DH;
+  const bf16_t* vg = a.v + (int64_t)b * a.bsv + h * DH;
+  const float unit = 1.4426950408889634f, cs = a.qscale * unit;
+  const int len = a.keypad ? a.len_k[b] : Tk;
+  const int kv_end = (a.keypad && len > 0 && len < Tk) ? len : Tk;       // keys at and beyond it get exactly zero weight
+  const int kv_lim = a.keypad ? (len < Tk ? len : Tk) : Tk;              // keys at and beyond it carry a bias
+  const int nkb = (kv_end + KBF - 1) / KBF;
+  const int nslice = (Tq + QS - 1) / QS, ngroup = (nslice + FW - 1) / FW;
+  const u32x4 rs_k = make_rsrc(kg, (unsigned)(((int64_t)(Tk - 1) * a.ldk + DH) * 2));
+  const u32x4 rs_v = make_rsrc(vg, (unsigned)(((int64_t)(Tk - 1) * a.ldv + DH) * 2));
+  const int ldk2 = (int)a.ldk * 2, ldv2 = (int)a.ldv * 2;
+  // block image = KBF * CH chunks of 16 B; LDS slot n = tid + 512 i holds chunk (n % CH) ^ swizzle of row n / CH
+  auto issue_block = [&](int kb, int buf) __attribute__((always_inline)) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int i = 0; i < KBF * CH / 512; ++i) {
+      const int n = t + 512 * i, row = n / CH, ch = (n - row * CH) ^ ((row >> 2) & 3);
+      const unsigned dst = (unsigned)(w + FW * i) * 1024u + (unsigned)buf * L::IMG_B;
+      dma16(rs_k, lds_base + L::K0 + dst, (kb * KBF + row) * ldk2 + ch * 16);
+      dma16(rs_v, lds_base + L::V0 + dst, (kb * KBF + row) * ldv2 + ch * 16);
+    }
+  };
+  // lane constants of the LDS addressing (as in the backward: row reads for the 32x32x16 A operand, transposed reads)
+  const int sw_c = (c >> 2) & 3;
+  const int rrd0 = c * ROWB + 16 * (g ^ sw_c), rrd1 = c * ROWB + 16 * ((2 + g) ^ sw_c);
+  const int trs_lo = (4 * g + qq) * ROWB + 16 * ((2 * (G & 1) + (p4 >> 1)) ^ g) + 8 * (p4 & 1);
+  const int trs_hi = (4 * g + qq + 8) * ROWB + 16 * ((2 * (G & 1) + (p4 >> 1)) ^ (g + 2)) + 8 * (p4 & 1);
+  char* const ost = smem + L::OST0 + w * L::OST_B;
+
+  issue_block(0, 0);
+  int it = 0;                                                             // blocks consumed so far (buffer = it & 1)
+  for (int grp = 0; grp < ngroup; ++grp) {
+    const int sl = grp * FW + w;                                          // this wave's slice (may lie beyond the last one: computes on zeros)
+    const int q = sl * QS + c;
+    const bool q_ok = q < Tq;
+    const int64_t row_g = (int64_t)bh * Tq + (q_ok ? q : 0);
+    bf16x8 qf[KS];
+    {
+      const bf16x8 zero = {};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(qg + (int64_t)(q_ok ? q : 0) * a.ldq + 16 * ks + 8 * g);
+        qf[ks] = q_ok ? x : zero;
+      }
+    }
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) oacc[db][v] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kb = 0; kb < nkb; ++kb, ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's pieces of block `it` have landed
+      __syncthreads();                                                    // everyone's have, and everyone has left the other buffer
+      {
+        const int nkb_next = kb + 1 < nkb ? kb + 1 : 0;
+        if (kb + 1 < nkb || grp + 1 < ngroup) issue_block(nkb_next, (it + 1) & 1);
+      }
+      const char* kim = smem + L::K0 + (it & 1) * L::IMG_B;
+      const char* vim = smem + L::V0 + (it & 1) * L::IMG_B;
+      const int K0 = kb * KBF;
+      // S^T of tile kt, one k-step (MFMA) at a time.  (Issuing the product of tile kt + 1 in pieces between the groups of the
+      // vector work of tile kt was measured: 45 -> 50 us at T = 500 - the second wave on the SIMD already fills the matrix
+      // pipe, the extra uniform branches and scheduling fences only cost.)
+      f32x16 sn;
+      bf16x8 kf[3];
+      auto ro_of = [&](int ks) __attribute__((always_inline)) { return ((ks & 1) ? rrd1 : rrd0) + 64 * (ks >> 1); };
+      auto s_begin = [&](int kt) __attribute__((always_inline)) {
+        const char* kimb = kim + 32 * kt * ROWB;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sn[v] = 0.f;
+        kf[0] = *reinterpret_cast<const bf16x8*>(kimb + ro_of(0));
+        kf[1] = *reinterpret_cast<const bf16x8*>(kimb + ro_of(1));
+      };
+      auto s_step = [&](int kt, int ks) __attribute__((always_inline)) {
+        const char* kimb = kim + 32 * kt * ROWB;
+        if (ks + 2 < KS) kf[(ks + 2) % 3] = *reinterpret_cast<const bf16x8*>(kimb + ro_of(ks + 2));
+        if constexpr ((ABL & 4) == 0) sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks % 3], qf[ks], sn, 0, 0, 0);
+        else asm volatile("" ::"v"(kf[ks % 3]));
+      };
+#pragma unroll 1
+      for (int pr = 0; pr < 2; ++pr) {
+        if (K0 + 64 * pr >= kv_end) break;                                // wave-uniform
+        uint32_t wA = 0xffffffffu, wB = 0xffffffffu;
+        if constexpr (DROP) {
+          const int wi = kb * (KBF / 32) + 2 * pr + g;
+          uint32_t mine;
+          if (a.keep_ready) {                                             // wave-uniform
+            mine = (q_ok && wi < a.nw) ? a.keep[row_g * a.nw + wi] : 0u;
+          } else {
+            mine = attn_keep_word(a.key, a.inner0, a.idx32, (uint64_t)(row_g * a.nw + wi), a.t16);
+            if (a.keep && q_ok && wi < a.nw) a.keep[row_g * a.nw + wi] = mine;
+          }
+          halves(mine, wA, wB);                                           // the lower half's word (tile 2 pr) and the upper half's (2 pr + 1)
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int kt = 2 * pr + t2, key0 = K0 + 32 * kt;
+          if (key0 >= kv_end) break;                                      // wave-uniform
+          s_begin(kt);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) s_step(kt, ks);
+          f32x16 s = sn;
+          // ---- first V^T fragments on their way while the vector work runs
+          const char* vimb = vim + 32 * kt * ROWB;
+          auto o2_of = [&](int i) __attribute__((always_inline)) { return 16 * (i / DB) * ROWB + 64 * (i % DB); };
+          bf16x8 vt = cat(lds_tr(vimb + trs_lo + o2_of(0)), lds_tr(vimb + trs_hi + o2_of(0)));
+          // ---- scores -> probabilities (base 2); keys of this lane: key0 + 8 j + 4 g + r  <->  s[4 j + r]
+          const bool edge = key0 + 32 > kv_lim;                           // wave-uniform
+          if (edge) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const int key = key0 + 8 * (v >> 2) + 4 * g + (v & 3);
+              float x = s[v] * cs;
+              if (key >= Tk) x = -INFINITY;
+              else if (key >= kv_lim) x += NEG_BIAS * unit;
+              s[v] = x;
+            }
+          }
+          float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+          for (int v = 3; v < 15; v += 2) tmax = fmaxf(fmaxf(tmax, s[v]), s[v + 1]);
+          tmax = fmaxf(tmax, s[15]);
+          if (!edge) tmax *= cs;
+          {
+            float t_lo, t_hi;
+            halves(tmax, t_lo, t_hi);
+            tmax = fmaxf(t_lo, t_hi);
+          }
+          const float m_new = fmaxf(m_run, tmax);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+          m_run = m_new;
+          const float sc = edge ? 1.f : cs;
+          float lsum = 0.f;
+          const uint32_t wg = (t2 == 0 ? wA : wB) >> (4 * g);
+          if (!(ABL & 8) && __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+              for (int v = 0; v < 16; ++v) oacc[db][v] *= alpha;
+          }
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float p = (ABL & 1) ? __builtin_fmaf(s[v], sc, -m_new) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], sc, -m_new));
+            lsum += p;
+            if constexpr (DROP) {
+              const int mk = __builtin_amdgcn_sbfe(wg, 8 * (v >> 2) + (v & 3), 1);
+              s[v] = __builtin_bit_cast(float, __builtin_bit_cast(int, p) & mk);
+            } else {
+              s[v] = p;
+            }
+          }
+          l_run = __builtin_fmaf(l_run, alpha, lsum);
+          bf16x8 pf[2];
+          pf[0] = pack8(s, 0);
+          pf[1] = pack8(s, 1);
+          // ---- O^T += V^T.P^T
+#pragma unroll
+          for (int i = 0; i < 2 * DB; ++i) {
+            bf16x8 nvt = vt;
+            if (i + 1 < 2 * DB) nvt = cat(lds_tr(vimb + trs_lo + o2_of(i + 1)), lds_tr(vimb + trs_hi + o2_of(i + 1)));
+            if constexpr ((ABL & 2) == 0) oacc[i % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pf[i / DB], oacc[i % DB], 0, 0, 0);
+            else asm volatile("" ::"v"(vt), "v"(pf[i / DB]));
+            vt = nvt;
+          }
+        }
+      }
+    }
+    // ---- this slice is complete: O = O^T^T * keep_scale / l, lse = (m + log2 l) ln 2
+    {
+      float l_lo, l_hi;
+      halves(l_run, l_lo, l_hi);
+      const float l = l_lo + l_hi;
+      const float inv = (DROP ? a.keep_scale : 1.f) / l;
+      if (g == 0 && q_ok) a.lse[(int64_t)bh * Tq + q] = (m_run + __log2f(l)) * 0.6931471805599453f;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x16& x = oacc[db];
+          const bf16x4 o4 = {(bf16_t)(x[4 * j] * inv), (bf16_t)(x[4 * j + 1] * inv), (bf16_t)(x[4 * j + 2] * inv), (bf16_t)(x[4 * j + 3] * inv)};
+          *reinterpret_cast<bf16x4*>(ost + c * ROWB + (32 * db + 8 * j + 4 * g) * 2) = o4;
+        }
+      // the same wave reads back what it wrote (LDS operations of one wave complete in order): whole rows to memory
+#pragma unroll
+      for (int i = 0; i < QS * CH / 64; ++i) {
+        const int n = lane + 64 * i, row = n / CH, ch = n % CH, qo = sl * QS + row;
+        const bf16x8 val = *reinterpret_cast<const bf16x8*>(ost + row * ROWB + ch * 16);
+        if (qo < Tq) *reinterpret_cast<bf16x8*>(a.o + (int64_t)b * a.bso + (int64_t)qo * a.ldo + h * DH + ch * 8) = val;
+      }
+    }
+  }
+}
+
 }  // namespace a2
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+static int g_opt_fwd_ablate = 0;          // diagnostic: timing-only ablations of the wide forward (wrong results)
 static int g_opt_mha_fused = 1;           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
 int neurst_attention2_set_option(const char* name, int value) {
   if (!strcmp(name, "mha_fused")) { g_opt_mha_fused = value; return 1; }
+  if (!strcmp(name, "mha_fwd_ablate")) { g_opt_fwd_ablate = value; return 1; }
   return 0;
 }
 
@@ -517,5 +779,46 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
   if (e != hipSuccess) { neurst_set_error("mha2_bwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
   kern<<<dim3((unsigned)(p.B * p.H)), 256, smem, s>>>(a);
   NEURST_CHECK_LAUNCH("mha2_bwd");
+  return NEURST_OK;
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+bool neurst_mha2_fwd_eligible(const Mha2FwdProblem& p) {
+  if (!g_opt_mha_fused || p.dtype != NEURST_BF16 || p.dh != 96) return false;
+  if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
+  if (p.B * p.H > 65535 * 16) return false;
+  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128)) return false;
+  auto al16 = [](const void* x, int64_t ld) { return ((uintptr_t)x & 15) == 0 && (ld * 2) % 16 == 0; };
+  if (!al16(p.q, p.ldq) || !al16(p.k, p.ldk) || !al16(p.v, p.ldv) || !al16(p.o, p.ldo)) return false;
+  if ((p.bsq * 2) % 16 || (p.bsk * 2) % 16 || (p.bsv * 2) % 16 || (p.bso * 2) % 16) return false;
+  if (p.Tk * p.ldk * 2 >= (1ll << 31) || p.Tk * p.ldv * 2 >= (1ll << 31)) return false;   // 32-bit LDS-DMA offsets
+  return true;
+}
+int neurst_mha2_fwd_launch(const Mha2FwdProblem& p, hipStream_t s) {
+  a2::FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = (const bf16_t*)p.q; a.k = (const bf16_t*)p.k; a.v = (const bf16_t*)p.v; a.o = (bf16_t*)p.o; a.lse = p.lse;
+  a.keep = p.rate > 0.f ? p.keep : nullptr; a.keep_ready = a.keep ? p.keep_ready : 0; a.len_k = p.len_k;
+  a.ldq = p.ldq; a.ldk = p.ldk; a.ldv = p.ldv; a.ldo = p.ldo; a.bsq = p.bsq; a.bsk = p.bsk; a.bsv = p.bsv; a.bso = p.bso;
+  a.B = (int)p.B; a.H = (int)p.H; a.Tq = (int)p.Tq; a.Tk = (int)p.Tk; a.nw = (int)cdiv64(p.Tk, 32);
+  a.keypad = p.mask_mode == NEURST_MASK_KEYPAD;
+  a.key = p.key; a.inner0 = fmix32(p.key); a.t16 = p.rate > 0.f ? attn_threshold16(p.rate) : 0u;
+  a.idx32 = (double)p.B * (double)p.H * (double)p.Tq * (double)a.nw * 4.0 < 4294967296.0;
+  a.qscale = 1.0f / sqrtf((float)p.dh);
+  a.keep_scale = keep_scale(p.rate);
+  const size_t smem = a2::LdsF<96>::BYTES;
+  auto kern = p.rate > 0.f ? a2::mha2_fwd_kernel<96, true> : a2::mha2_fwd_kernel<96, false>;
+  switch (g_opt_fwd_ablate) {
+    case 1: kern = a2::mha2_fwd_kernel<96, false, 1>; break;
+    case 2: kern = a2::mha2_fwd_kernel<96, false, 2>; break;
+    case 4: kern = a2::mha2_fwd_kernel<96, false, 4>; break;
+    case 8: kern = a2::mha2_fwd_kernel<96, false, 8>; break;
+    case 15: kern = a2::mha2_fwd_kernel<96, false, 15>; break;
+    default: break;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) { neurst_set_error("mha2_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
+  kern<<<dim3((unsigned)(p.B * p.H)), 512, smem, s>>>(a);
+  NEURST_CHECK_LAUNCH("mha2_fwd");
   return NEURST_OK;
 }

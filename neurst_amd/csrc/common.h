@@ -93,15 +93,19 @@ __device__ __forceinline__ uint32_t attn_keep_word(uint32_t key, uint32_t inner0
     }
   }
   uint32_t lt = 0u;
+  // the threshold as a per-lane value on purpose: as a wave-uniform one the 16 digit tests become 16 SGPR-pair masks that
+  // live across the caller's whole loop (measured in the attention forward: 56 spilled SGPRs, 177 v_readlane in the loop)
+  uint32_t tv = t16;
+  asm volatile("" : "+v"(tv));
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     if (k && (k & 3) == 0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) c[j] = xorshift32(c[j]);
     }
-    const uint32_t W = c[k & 3], m = 0u - ((t16 >> k) & 1u);     // m: wave-uniform all-ones / zero
+    const uint32_t W = c[k & 3], m = (uint32_t)__builtin_amdgcn_sbfe((int)tv, k, 1);   // all-ones / zero from digit k
     const uint32_t x = lt ^ W;
-    lt = (x & m) | (~x & lt);                                     // bit k of t16 set: lt | W, clear: lt & W
+    lt = (x & m) | (~x & lt);                                     // digit set: lt | W, clear: lt & W
   }
   return lt;
 }

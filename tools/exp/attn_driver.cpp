@@ -22,14 +22,14 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&keep, kbb)); CK(hipMalloc(&ws, wsb ? wsb : 16));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (float rate : {0.0f, 0.1f}) {
-    for (int which = 0; which < 3; ++which) {
-      neurst_set_option("mha_fused", which == 2 ? 2 : 0);
+    for (int which = 0; which < 4; ++which) {
+      neurst_set_option("mha_fused", which >= 2 ? 2 : 0);
       const int iters = 20;
       float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; ++i) {
-          int rc = which == 0
+          int rc = (which == 0 || which == 3)
             ? neurst_mha_fwd_train(qkv, qkv + d, qkv + 2 * d, o, lse, rate > 0 ? keep : nullptr, 3 * d, 3 * d, 3 * d, d, B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, rate, 123u, NEURST_BF16, nullptr)
             : neurst_mha_bwd_train_ws(qkv, qkv + d, qkv + 2 * d, o, d_o, lse, rate > 0 ? keep : nullptr, delta, dqkv, dqkv + d, dqkv + 2 * d, 3 * d, 3 * d, 3 * d, d, 3 * d, 3 * d, 3 * d,
                              B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, rate, 123u, NEURST_BF16, ws, wsb, nullptr);
@@ -38,10 +38,24 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
-      double fl = 4.0 * B * H * T * T * dh * (which ? 2.5 : 1.0);
-      printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which == 2 ? "bwd(fused) " : which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
+      double fl = 4.0 * B * H * T * T * dh * ((which == 1 || which == 2) ? 2.5 : 1.0);
+      printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which == 3 ? "fwd(wide)  " : which == 2 ? "bwd(fused) " : which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
     }
   }
+  for (int abl : {0, 1, 2, 4, 8, 15}) {   // timing-only ablations of the wide forward
+    neurst_set_option("mha_fused", 2);
+    neurst_set_option("mha_fwd_ablate", abl);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 20; ++i)
+        neurst_mha_fwd_train(qkv, qkv + d, qkv + 2 * d, o, lse, nullptr, 3 * d, 3 * d, 3 * d, d, B, H, T, T, dh, NEURST_MASK_KEYPAD, lens, 0.f, 123u, NEURST_BF16, nullptr);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("fwd(wide) ablate %2d: %8.1f us\n", abl, ms * 1e3 / 20);
+  }
+  neurst_set_option("mha_fwd_ablate", 0);
   {   // phase stamps of workgroup 0 of the fused backward (cycles)
     long long* st; CK(hipMalloc(&st, 64 * 8)); CK(hipMemset(st, 0, 64 * 8));
     neurst_debug_mha2_stamps(st);
