@@ -24,6 +24,8 @@
 #ifndef DKV_WPE
 #define DKV_WPE 3
 #endif
+// head sizes above 128 (the KD attention, dh = 192) get two waves per SIMD: at three (168 registers) those instantiations
+// spilled 80-130 registers per lane to scratch
 #define ATT_OCC(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 // stops the instruction scheduler from hoisting every LDS fragment read of a phase to its start (which costs
 // 100+ registers and the occupancy with them); other waves hide the LDS latency instead
@@ -265,7 +267,7 @@ __device__ __forceinline__ void store4(T* __restrict__ row, int c0, int dh, f32x
 // ================================================================== forward
 // workgroup = 64 queries (16 per wave); lane l works for query (l & 15); S^T = K.Q^T, O^T = V^T.P^T
 template <typename T, int DH, bool FULL>
-__global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : FWD_WPE)) mha_fwd_kernel(AttnArgs a) {
   constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);            // [64][LDK]
@@ -375,7 +377,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(FWD_WPE) mha_fwd_kernel(AttnArgs 
 // ================================================================== backward: delta + dQ
 // lane l works for query (l & 15): S^T = K.Q^T, dP^T = V.dO^T, dQ^T = K^T.dS^T; also writes delta = rowsum(dO * O)
 template <typename T, int DH, bool FULL>
-__global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DQ_WPE)) mha_bwd_dq_kernel(AttnArgs a) {
   constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);             // [64][LDK]
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(256) ATT_OCC(DQ_WPE) mha_bwd_dq_kernel(AttnArg
 // ================================================================== backward: dK, dV
 // workgroup = 64 keys (16 per wave); lane l works for key (l & 15): S = Q.K^T, dP = dO.V^T, dV^T = dO^T.P, dK^T = Q^T.dS
 template <typename T, int DH, bool FULL>
-__global__ void __launch_bounds__(256) ATT_OCC(DKV_WPE) mha_bwd_dkv_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DKV_WPE)) mha_bwd_dkv_kernel(AttnArgs a) {
   constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Qs = reinterpret_cast<T*>(smem);                 // [64][LDK]
