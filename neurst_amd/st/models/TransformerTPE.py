@@ -92,6 +92,8 @@ def variable_specs(args, name='transformer'):
 
 
 _STORES = {}
+# the CTC branch behind the semantic encoder instead of beside it (see _encode); NEURST_DEFER_CTC=0: the round-1 order
+_DEFER_CTC = os.environ.get('NEURST_DEFER_CTC', '1') != '0'
 
 
 def get_variable_store(args, name, device):
@@ -145,7 +147,7 @@ class TransformerTPE(Seq2SeqModel):
         if self.args.use_horovod:
             raise NotImplementedError('use_horovod: data parallelism is one process per GPU over RCCL (torch.distributed)')
         self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 64) * (1 << 20)) // 256 * 256, 256),
-                                     producer_streams=lambda: (self.graph.wgrad_stream,))
+                                     producer_streams=lambda: (self.graph.wgrad_stream, self._ctc_stream))
         self.graph.on_param_grad = self.bucketer.param_done
         self.graph.on_node_done = self.bucketer.node_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
@@ -218,17 +220,37 @@ class TransformerTPE(Seq2SeqModel):
         a = self.args
         g = self.graph
         encoded_am, len_encoded_am = self.encoder(features=feature, len_feas=len_fea)
-        with G.variable_scope(self.decoder.name or 'decoder'):
-            logits_am, _, len_logits_am = self.decoder_ctc(encoded=encoded_am, len_encoded=len_encoded_am)
-        loss_ctc = None
-        # The CTC branch (loss, its gradient, greedy decode) only meets the rest of the step again at the loss mix
-        # and in the backward of the CTC head, so it runs on its own HIP stream beside the semantic encoder and
-        # the decoder - unless shrink_layer needs the arg-max right away.
+        # The CTC branch (head GEMM, loss, its gradient, greedy decode) only meets the rest of the step again at the loss
+        # mix and in the backward of the CTC head, so it runs on its own HIP stream - unless shrink_layer needs the arg-max
+        # right away.  It is enqueued BEHIND the semantic encoder (the stream waits for everything the main stream holds
+        # at that point): its kernels then run beside the decoder's chain of decoder-size launches instead of sharing the
+        # chip with the semantic encoder's GEMMs, and the head GEMM leaves the main stream.  Measured 14.14 -> 14.06 ms
+        # per step: kernels of two HIP streams hardly overlap on this part (tools/exp/cu_mask.py: a chain of 200 small
+        # GEMMs beside 10 large ones takes the SUM of both, and confining the large ones to a CU-masked stream
+        # (hipExtStreamCreateWithCUMask, 64-192 CUs) makes the pair 1.5-4 x slower than running them one after the other).
         side = None
-        if want_ctc_grad and not a.model.shrink_layer and logits_am.is_cuda and g.side_streams:
+        if want_ctc_grad and not a.model.shrink_layer and encoded_am.is_cuda and g.side_streams:
             if self._ctc_stream is None:
                 self._ctc_stream = torch.cuda.Stream(device=self.device)
             side = self._ctc_stream
+        defer = side is not None and _DEFER_CTC and a.model.use_semantic_encoder
+        if defer:
+            encoded, len_encoded = self.encoder_mt(features=encoded_am, len_feas=len_encoded_am)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with G.variable_scope(self.decoder.name or 'decoder'):
+                    logits_am, _, len_logits_am = self.decoder_ctc(encoded=encoded_am, len_encoded=len_encoded_am)
+                if g.dtype == ops.F32 and self.keep_logits:
+                    self.last['logits_am'] = logits_am.clone()      # the fp32 gradient overwrites the logits in place
+                loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],
+                                                    len_labels=batch['len_aux_label'], grad_scale=ctc_scale)
+                preds_am, len_preds_am = self.ctc_decode(argmax_am, len_logits_am)
+            self._ctc_pending = True
+            self.last['preds_am'], self.last['len_preds_am'] = preds_am, len_preds_am
+            return encoded, len_encoded, logits_am, loss_ctc
+        with G.variable_scope(self.decoder.name or 'decoder'):
+            logits_am, _, len_logits_am = self.decoder_ctc(encoded=encoded_am, len_encoded=len_encoded_am)
+        loss_ctc = None
         if want_ctc_grad:
             if g.dtype == ops.F32 and self.keep_logits:
                 self.last['logits_am'] = logits_am.clone()      # the fp32 gradient overwrites the logits in place
@@ -310,11 +332,22 @@ class TransformerTPE(Seq2SeqModel):
                 encoded_feat = extract_feat(encoded, bert_feat, a)
                 mse_partial = compute_kd_loss(bert_feat, encoded_feat, a.model.kd.loss_type, grad_scale=w_kd)
                 mse_numel = encoded_feat.numel()
-            self._join_ctc_stream()
-            out4 = ops.loss_combine(xent, loss_ctc, mse_partial, mse_numel, B, xent.shape[1], w_ast, w_ctc, w_kd, self.device)
+            # Nothing on the main stream needs the CTC branch before the loss mix: when the CTC head's backward runs as an
+            # early node on the weight-gradient stream, that stream waits for the CTC stream and the main stream goes
+            # straight into the decoder's backward; the loss mix follows the backward.
+            lazy = self._ctc_pending and _DEFER_CTC and bool(tape.early) and g.side_streams
+            if lazy:
+                g.early_stream = self._ctc_stream
+            else:
+                self._join_ctc_stream()
+                out4 = ops.loss_combine(xent, loss_ctc, mse_partial, mse_numel, B, xent.shape[1], w_ast, w_ctc, w_kd, self.device)
             self.last.update(encoded=encoded, len_encoded=len_encoded, loss_ctc_vec=loss_ctc, xent=xent)
             tape.backward()           # `optimizer.compute_gradients(loss)` (:472)
+            g.early_stream = None
             g.join_side_streams()
+            if lazy:
+                self._join_ctc_stream()
+                out4 = ops.loss_combine(xent, loss_ctc, mse_partial, mse_numel, B, xent.shape[1], w_ast, w_ctc, w_kd, self.device)
             g.tape = None
         if self.frozen:               # frozen_scope filter (:171-183)
             for p in self.store.vars.values():

@@ -218,6 +218,9 @@ class Graph:
         self.side_keep = []
         self.side_used = False
         self.in_early = False
+        self.early_stream = None     # stream for early backward nodes (default: the weight-gradient stream)
+        self.early_used = set()
+        self.early_ptrs = {}         # storage -> early stream that writes it
         self.side_writes = set()
         # Encoder-size weight gradients (thousands of rows) are not launched one by one: each has only 12-48 output tiles
         # of 256 x 192, and the whole-K tile kernel runs one workgroup per tile.  They are collected until their tiles fill
@@ -324,8 +327,15 @@ class Graph:
             return False
         if self.wgrad_stream is None:
             self.wgrad_stream = torch.cuda.Stream(device=self.store.grads.device)
-        side = self.wgrad_stream
-        side.wait_stream(torch.cuda.current_stream())
+        side = self.early_stream
+        if side is None:
+            side = self.wgrad_stream
+            side.wait_stream(torch.cuda.current_stream())
+        else:
+            # early_stream produced the node's output gradient itself and already follows everything else the node reads
+            # (the activations of the forward, the zeroed gradient arena): no wait for the main stream, the node starts as
+            # soon as the loss kernels before it are done
+            self.early_used.add(side)
         self.in_early = True
         try:
             with torch.cuda.stream(side):
@@ -339,9 +349,13 @@ class Graph:
         """Tensors produced on the second stream: the main stream waits for it before it updates one of them in place;
         a plain READ on the main stream must be preceded by that wait too (callers: only gradients that are always
         accumulated into before anything reads them)."""
+        st = self.early_stream if self.in_early else None
         for t in tensors:
             p = t.untyped_storage().data_ptr()
-            self.side_reads.add(p)
+            if st is not None:
+                self.early_ptrs[p] = st         # produced on the early nodes' own stream: wait for THAT stream only
+            else:
+                self.side_reads.add(p)
             self.side_writes.add(p)
         self.side_keep.append(tensors)
 
@@ -351,7 +365,7 @@ class Graph:
         p = t.untyped_storage().data_ptr()
         if p in self.side_writes:
             self.side_writes.discard(p)
-            if p in self.side_reads:
+            if p in self.side_reads or p in self.early_ptrs:
                 self.before_inplace_write(t)
 
     # ---- grouped weight gradients ----------------------------------------------------------------------------
@@ -425,6 +439,10 @@ class Graph:
         wait for the side stream's tail (covers every reader enqueued so far)."""
         if self.pending_reads and t.untyped_storage().data_ptr() in self.pending_reads:
             self.flush_wgrads()                 # a gradient still waiting for its group reads this tensor: launch it first
+        if self.early_ptrs:
+            st = self.early_ptrs.pop(t.untyped_storage().data_ptr(), None)
+            if st is not None:
+                torch.cuda.current_stream().wait_stream(st)
         if self.side_reads and t.untyped_storage().data_ptr() in self.side_reads:
             ev = torch.cuda.Event()
             ev.record(self.wgrad_stream)
@@ -437,6 +455,10 @@ class Graph:
         if self.side_used:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self.side_used = False
+        for st in self.early_used:
+            torch.cuda.current_stream().wait_stream(st)
+        self.early_used.clear()
+        self.early_ptrs.clear()
         self.side_reads.clear()
         self.side_writes.clear()
         self.side_keep.clear()

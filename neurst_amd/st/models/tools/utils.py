@@ -83,7 +83,7 @@ def _linear(inputs, w, b, units, relu, layout, out_dtype, stop_gradient, early_b
             if bw is b and g.defer_wgrad(dy2, x2, w, layout, b):
                 pass                 # encoder-size layer: goes out with its group (graph.flush_wgrads reports the parameters)
             else:
-                side = g.side_stream_for(M, dy2.device)
+                side = None if g.in_early else g.side_stream_for(M, dy2.device)   # an early node already runs off the main stream
                 if side is not None:     # small layer: weight (and bias) gradient beside the data-gradient chain
                     g.run_on_side(side, lambda: _wgrad(dy2, x2, w, layout, bw), dy2, x2)
                 else:
