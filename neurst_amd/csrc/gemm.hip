@@ -44,8 +44,13 @@ __device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __re
 constexpr int EPI_LD = 68;                                   // fp32 row stride of the per-wave epilogue tile
 constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;               // 4 waves x 32 rows x 68 floats
 
+// waves per SIMD the register allocation must leave room for: 3 for the bf16 NN kernel (K-tiles of 32: 32 KiB of LDS per
+// workgroup, three of them hide each other's load latency), 1 elsewhere (LDS already limits those to one or two)
+template <typename T, bool TA, bool TB_KCONTIG, bool FAST, int NS>
+constexpr int gemm_min_waves() { return (sizeof(T) == 2 && !TA && !TB_KCONTIG && FAST && NS == 2) ? 3 : 1; }
 template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST, int SUMOP = 0, int NS = 2>
-__global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm_min_waves<T, TA, TB_KCONTIG, FAST, NS>())))
+gemm_kernel(GemmArgs g) {
   // TB_KCONTIG: B stored [N][K] (trans_b = 1); otherwise B stored [K][N].  TA: A stored [K][M].
   // FAST (bf16, aligned operands): full K-tiles go global -> LDS directly (no VGPR staging).
   // NS = LDS stages.  2: three workgroups per CU hide each other's load latency (large grids).  4: for grids of at most
@@ -231,6 +236,83 @@ __global__ void __launch_bounds__(NT) gemm_kernel(GemmArgs g) {
         const int64_t col = wcol0 + j * 16 + lane;
         if (col < g.N && sacc[j][0] != 0.f) atomicAdd(g.opsum + col, sacc[j][0]);
       }
+    }
+  }
+  // ---- interior wave tiles of bf16 problems (every one at M = B*T rows): branch-free store passes.  What they read from
+  // global memory - the ReLU gate's source, the old C when accumulating - is requested for a whole half-tile (4 passes)
+  // at once, the gate one half ahead.  In the general passes below every such load is followed by s_waitcnt vmcnt(0),
+  // which also waits for the previous pass's store: 16 dependent round trips to HBM per tile (the ffn2 data gradient
+  // with its gate took 131 us in the step against 99 us on cache-resident operands).
+  if constexpr (sizeof(T) == 2 && SUMOP == 0) {
+    const bool interior = g.split_k <= 1 && g.c_vec && wrow0 + 64 <= g.M && wcol0 + 64 <= g.N;
+    if (__builtin_amdgcn_readfirstlane((int)interior)) {
+      const int cc = (lane & 7) * 8;
+      const int64_t base = (wrow0 + (lane >> 3)) * g.ldc + wcol0 + cc;     // + (half * 32 + pass * 8) * ldc
+      const bf16_t* const rsb = reinterpret_cast<const bf16_t*>(rs);
+      const bool gate = rsb != nullptr, accum = g.accumulate != 0;
+      bf16x8 pg[2][4];
+      f32x4 po[4][sizeof(TC) == 2 ? 1 : 2];
+      auto fetch_gate = [&](int half) __attribute__((always_inline)) {
+        if (gate) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) pg[half][pass] = *reinterpret_cast<const bf16x8*>(rsb + base + (int64_t)(half * 32 + pass * 8) * g.ldc);
+        }
+      };
+      fetch_gate(0);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (accum) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const TC* cp = C + base + (int64_t)(half * 32 + pass * 8) * g.ldc;
+            po[pass][0] = *reinterpret_cast<const f32x4*>(cp);             // 8 bf16 or the first 4 floats
+            if constexpr (sizeof(TC) == 4) po[pass][1] = *reinterpret_cast<const f32x4*>(cp + 4);
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(ii * 16 + (lane >> 4) * 4 + r) * EPI_LD + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
+        if (half == 0) fetch_gate(1);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int rr = pass * 8 + (lane >> 3);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + rr * EPI_LD + cc);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + rr * EPI_LD + cc + 4);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (gate) {
+            const bf16x8 m = pg[half][pass];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)m[e] > 0.f ? v[e] : 0.f;
+          }
+          TC* cp = C + base + (int64_t)(half * 32 + pass * 8) * g.ldc;
+          if constexpr (sizeof(TC) == 2) {
+            if (accum) {
+              const bf16x8 old = __builtin_bit_cast(bf16x8, po[pass][0]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            STORE_C(reinterpret_cast<bf16x8*>(cp), o);
+          } else {
+            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            if (accum) { o0 += po[pass][0]; o1 += po[pass][1]; }
+            STORE_C(reinterpret_cast<f32x4*>(cp), o0);
+            STORE_C(reinterpret_cast<f32x4*>(cp + 4), o1);
+          }
+        }
+      }
+      return;
     }
   }
 #pragma unroll
