@@ -652,6 +652,80 @@ __global__ void __launch_bounds__(256) ls_xent_kernel(const float* __restrict__ 
     grow[i] = from_f32<TG>(g * (p * sumsoft - soft));
   }
 }
+// Register-resident rows (as ctc_frame_reg_kernel): V % 4 == 0, V <= 256 * 4 * NV4, 16-byte aligned rows.  One HBM read
+// of the row in 16-byte lanes, maximum first and then one exp per element, one vector store of the gradient
+// (the LDS-cached kernel above reads the row with 4-byte lanes and evaluates exp twice: 59 us at 1280 x 10000).
+template <typename TG, int NV4>
+__global__ void __launch_bounds__(256) ls_xent_reg_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ len_labels, float* __restrict__ xent, TG* __restrict__ grad,
+                                                         int64_t L, int V, float conf, float grad_scale) {
+  __shared__ float redm[4], reds[4], redz[4];
+  const int64_t bl = blockIdx.x, b = bl / L, l = bl % L;
+  const int nv4 = V >> 2, tid = threadIdx.x;
+  const f32x4* row4 = reinterpret_cast<const f32x4*>(logits + bl * V);
+  TG* grow = grad + bl * V;
+  auto store4 = [&](int idx, f32x4 y) {
+    if constexpr (sizeof(TG) == 4) *reinterpret_cast<f32x4*>(grow + 4 * idx) = y;
+    else *reinterpret_cast<bf16x4*>(grow + 4 * idx) = bf16x4{(bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
+  };
+  const int len = len_labels[b];
+  if (l >= len) {
+    for (int idx = tid; idx < nv4; idx += 256) store4(idx, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (tid == 0) xent[bl] = 0.f;
+    return;
+  }
+  int lab = labels[bl];
+  lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+  f32x4 x[NV4];
+  float m = -INFINITY, zs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nv4) {
+      x[i] = row4[idx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { m = fmaxf(m, x[i][e]); zs += x[i][e]; }
+    } else {
+      x[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  const float x_lab = logits[bl * V + lab];      // read before any store: the fp32 gradient may overwrite the logits
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  zs = wave_sum(zs);
+  if ((tid & 63) == 0) { redm[tid >> 6] = m; redz[tid >> 6] = zs; }
+  __syncthreads();
+  m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  zs = redz[0] + redz[1] + redz[2] + redz[3];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[i][e] = expf(x[i][e] - m); sum += x[i][e]; }   // exp(-inf) = 0 for the unused tail
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) reds[tid >> 6] = sum;
+  __syncthreads();                               // also: every thread holds x_lab before the stores below
+  sum = reds[0] + reds[1] + reds[2] + reds[3];
+  const float lse = m + logf(sum);
+  const float low = (1.0f - conf) / (float)(V - 1);
+  const float inv_len = 1.0f / (float)len;
+  if (tid == 0) {
+    const float normalizing = -(conf * logf(conf) + (float)(V - 1) * low * logf(low + 1e-20f));
+    const float sum_logp = zs - (float)V * lse;
+    xent[bl] = (-(low * sum_logp + (conf - low) * (x_lab - lse)) - normalizing) * inv_len;
+  }
+  const float sumsoft = conf + (float)(V - 1) * low;
+  const float g = grad_scale * inv_len, k = g * sumsoft / sum, glow = g * low, gconf = g * conf;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nv4) {
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = x[i][e] * k - ((4 * idx + e == lab) ? gconf : glow);
+      store4(idx, y);
+    }
+  }
+}
 extern "C" int neurst_ls_xent_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* len_labels, float* xent, void* grad,
                                       int grad_dtype, int64_t B, int64_t L, int64_t V, float confidence, float grad_scale, void* stream) {
   NEURST_CHECK_ARG(logits && labels && len_labels && xent && grad, "ls_xent: null pointer");
@@ -660,7 +734,13 @@ extern "C" int neurst_ls_xent_fwd_bwd(const float* logits, const int32_t* labels
   NEURST_CHECK_ARG(use_cache || (const void*)grad != (const void*)logits, "ls_xent: in-place gradient needs V*4 <= 64 KiB");
   NEURST_CHECK_ARG(grad_dtype == NEURST_F32 || (const void*)grad != (const void*)logits, "ls_xent: bf16 gradient cannot alias the logits");
   const size_t shm = use_cache ? V * sizeof(float) : 0;
-  if (grad_dtype == NEURST_BF16)
+  const bool vec = V % 4 == 0 && ((uintptr_t)logits & 15) == 0 && ((uintptr_t)grad & 15) == 0 && V <= 256 * 4 * 16;
+#define LS_XENT_REG(TG, NV4) ls_xent_reg_kernel<TG, NV4><<<(unsigned)(B * L), 256, 0, as_stream(stream)>>>(logits, labels, len_labels, xent, (TG*)grad, L, (int)V, confidence, grad_scale)
+  if (vec && grad_dtype == NEURST_BF16) {
+    if (V <= 256 * 4 * 3) LS_XENT_REG(bf16_t, 3); else if (V <= 256 * 4 * 10) LS_XENT_REG(bf16_t, 10); else LS_XENT_REG(bf16_t, 16);
+  } else if (vec) {
+    if (V <= 256 * 4 * 3) LS_XENT_REG(float, 3); else if (V <= 256 * 4 * 10) LS_XENT_REG(float, 10); else LS_XENT_REG(float, 16);
+  } else if (grad_dtype == NEURST_BF16)
     ls_xent_kernel<bf16_t><<<(unsigned)(B * L), 256, shm, as_stream(stream)>>>(logits, labels, len_labels, xent, (bf16_t*)grad, L, (int)V, confidence, grad_scale, use_cache);
   else
     ls_xent_kernel<float><<<(unsigned)(B * L), 256, shm, as_stream(stream)>>>(logits, labels, len_labels, xent, (float*)grad, L, (int)V, confidence, grad_scale, use_cache);

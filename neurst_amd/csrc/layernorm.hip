@@ -340,7 +340,13 @@ static inline bool ln_vec_ok(int64_t C, int vec, const void* a, const void* b, c
 // Launch shape of ln_bwd_vec.  The tail of every workgroup adds 2 C column partials to dgamma / dbeta with atomics, so few,
 // fat workgroups win: measured on 16000 x 768 (rate 0.1): 512 x 256 threads 42.8 us, 512 x 512 35.0, 256 x 1024 33.8
 // (one workgroup of 16 waves per CU: 16 rows in flight per CU), 320 x 1024 42.6, 128 x 1024 44.1.
-static int ln_bwd_threads(int64_t rows) { return rows >= 4096 ? 1024 : 256; }
+// Decoder-size inputs (1280 rows) as well: 80 workgroups of 16 waves instead of 320 of 4 - a quarter of the atomic adds on
+// the same 2 C addresses; kernel alone 15 -> 6.6 us (NEURST_LN_BWD_SMALL_THREADS = 256 / 512 / 1024 for A/B timing).
+static int ln_small_threads() {
+  static const int v = [] { const char* e = getenv("NEURST_LN_BWD_SMALL_THREADS"); const int t = e ? atoi(e) : 1024; return (t == 256 || t == 512) ? t : 1024; }();
+  return v;
+}
+static int ln_bwd_threads(int64_t rows) { return rows >= 4096 ? 1024 : (rows >= 512 ? ln_small_threads() : 256); }
 extern "C" int64_t neurst_layernorm_bwd_blocks(int64_t rows) {
   const int64_t per = ln_bwd_threads(rows) / 64, cap = rows >= 4096 ? 256 : 512;
   const int64_t g = cdiv64(rows, per);

@@ -106,7 +106,7 @@ def bench_attn():
 
 
 def bench_ln():
-    rows, C = 16000, 768
+    rows, C = int(os.environ.get('LN_ROWS', '16000')), 768
     x = torch.randn(rows, C, device=DEV).to(torch.bfloat16)
     y = torch.randn(rows, C, device=DEV).to(torch.bfloat16)
     g = torch.ones(C, device=DEV)
