@@ -20,7 +20,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import neurst_amd  # noqa: E402,F401  (first: asks HIP for 6 hardware queues before the runtime starts, neurst_amd/__init__.py)
+import neurst_amd  # noqa: E402
+neurst_amd.want_hw_queues()   # before the HIP runtime starts: 6 hardware queues for the step's streams (neurst_amd/__init__.py)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

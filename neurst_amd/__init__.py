@@ -8,7 +8,7 @@ def want_hw_queues(n=6):
     its own.  Measured on MI355X (LUT step, one rank under torch.distributed.run; without / with the bucketed all-reduce
     path forced on): 4 queues 17.4 / 17.8 ms, 5: 16.5 / 17.2, 6: 16.6 / 16.9, 8: 16.5 / 22.3 (more queues than the step has
     streams is NOT harmless).  The variable is read when the HIP runtime starts, so this must run before the first
-    torch.cuda call of the process (importing this package first does that); NEURST_HW_QUEUES overrides the 6."""
+    torch.cuda call of the process."""
     try:
         cur = int(os.environ.get('GPU_MAX_HW_QUEUES', '') or 0)
     except ValueError:
@@ -17,4 +17,7 @@ def want_hw_queues(n=6):
         os.environ['GPU_MAX_HW_QUEUES'] = str(n)
 
 
-want_hw_queues(int(os.environ.get('NEURST_HW_QUEUES', '6')))
+# Importing the package changes nothing in the process: the programs that train (bench.py, st/bin/run_lut.py, the tests'
+# conftest) call want_hw_queues() themselves, first thing.  NEURST_HW_QUEUES in the environment asks for it at import.
+if os.environ.get('NEURST_HW_QUEUES'):
+    want_hw_queues(int(os.environ['NEURST_HW_QUEUES']))

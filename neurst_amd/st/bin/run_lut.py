@@ -188,6 +188,8 @@ def load_vocab(path):
 
 
 def main(argv=None):
+    from ... import want_hw_queues
+    want_hw_queues()      # before the HIP runtime starts: the step keeps 3-4 streams busy (neurst_amd/__init__.py)
     logging.basicConfig(level=logging.INFO, format='%(levelname)s(%(filename)s:%(lineno)d): %(message)s')
     parser = argparse.ArgumentParser()
     parser.add_argument('-m', type=str, dest='mode', default='train')

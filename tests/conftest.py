@@ -8,7 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-import neurst_amd  # noqa: E402,F401  (before any torch.cuda call: asks HIP for 6 hardware queues, neurst_amd/__init__.py)
+import neurst_amd  # noqa: E402
+neurst_amd.want_hw_queues()   # before any torch.cuda call: 6 hardware queues (neurst_amd/__init__.py)
 
 
 def pytest_configure(config):
