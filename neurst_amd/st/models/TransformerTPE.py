@@ -7,6 +7,7 @@ There is no TF session here: `train_step(batch)` runs what `sess.run(model.list_
 what `sess.run(model_infer.list_run, feed_dict)` ran.  `list_run` keeps the reference ordering as callables.
 """
 import os
+import weakref
 from collections import namedtuple
 
 import numpy as np
@@ -97,13 +98,20 @@ _DEFER_CTC = os.environ.get('NEURST_DEFER_CTC', '1') != '0'
 
 
 def get_variable_store(args, name, device):
-    """Variables are shared by name between the train and the infer model (tf.AUTO_REUSE, :148,:496)."""
+    """Variables are shared by name between the train and the infer model (tf.AUTO_REUSE, :148,:496).  The store (five
+    arenas of the parameter count) lives as long as the configuration object it was built for: when `args` is collected the
+    entry goes with it, so a process that builds one model after another does not pile up arenas."""
     key = (id(args), name)
-    if key not in _STORES:
+    ent = _STORES.get(key)
+    if ent is None:
         dtype = ops.BF16 if str(args.compute_dtype).lower() in ('bf16', 'bfloat16') else ops.F32
-        # the entry keeps `args` alive: a collected args object could hand its id() to a new configuration
-        _STORES[key] = (args, G.VariableStore(variable_specs(args, name), device, dtype, seed=1 if args.init_seed is None else args.init_seed))
-    return _STORES[key][1]
+        store = G.VariableStore(variable_specs(args, name), device, dtype, seed=1 if args.init_seed is None else args.init_seed)
+        try:
+            weakref.finalize(args, _STORES.pop, key, None)
+            ent = _STORES[key] = (None, store)
+        except TypeError:      # not weak-referenceable: keep `args` alive instead, a collected object could hand its id() on
+            ent = _STORES[key] = (args, store)
+    return ent[1]
 
 
 class TransformerTPE(Seq2SeqModel):

@@ -85,6 +85,24 @@ def test_variable_names_and_sizes_match_survey_inventory():
         assert 'transformer/TPEncoder/block_0/ff_hidden/dense_1/kernel' in names
 
 
+def test_variable_store_is_released_with_its_configuration():
+    """The store registry must not keep arenas alive after the configuration they belong to is gone
+    (a process that builds several models in turn)."""
+    import gc
+    from neurst_amd.st.layers.arguments import build_args
+    from neurst_amd.st.models import TransformerTPE as M
+    args = build_args(os.path.join(ROOT, 'configs', 'lut.yaml'), dim_output=50, compute_dtype='fp32')
+    for blk in (args.model.encoder, args.model.encoder2, args.model.decoder):
+        blk.num_blocks = 1
+    store = M.get_variable_store(args, 'transformer', torch.device('cpu'))
+    assert M.get_variable_store(args, 'transformer', torch.device('cpu')) is store      # shared by name (tf.AUTO_REUSE)
+    key = (id(args), 'transformer')
+    assert key in M._STORES
+    del args
+    gc.collect()
+    assert key not in M._STORES
+
+
 def test_lr_schedule_matches_oracle():
     from neurst_amd.st.models.model_tools import warmup_exponential_decay as w
     from oracle.ops import warmup_exponential_decay as wo
