@@ -288,10 +288,18 @@ int neurst_conv2d_ln_relu_fwd(const void* x, const float* w, const float* bias, 
                               const float* beta, void* conv_out, void* out, float* mean, float* rstd,
                               int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                               int kh, int kw, int sh, int sw, int dtype, void* stream);
-/* dgamma/dbeta/dw/dbias accumulate (+=, fp32 atomics); dx may be NULL (first layer). */
+/* dgamma/dbeta/dw/dbias accumulate (+=, fp32 atomics); dx may be NULL (first layer).  dconv_ws: workspace of conv_out's
+ * shape and type.  col_ws (may be NULL: the general weight-gradient kernel then runs, much slower): workspace of
+ * neurst_conv2d_bwd_workspace_bytes() bytes - the im2col image [pixels][kh kw Cin] that turns the weight gradient of a
+ * bf16 3x3 layer with Cin % 8 == 0 into one split-K GEMM over the pixels (0 bytes for other shapes and for fp32).
+ * bf16 layers take implicit-GEMM MFMA kernels (3x3, Cin and Cout in {32, 64}) or a registers-resident small-K kernel
+ * (kh kw Cin <= 32, the first layer); neurst_set_option("conv_fast", 0) forces the general kernels. */
+int64_t neurst_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kh, int kw,
+                                          int sh, int sw, int dtype);
 int neurst_conv2d_ln_relu_bwd(const void* dout, const void* x, const float* w, const float* gamma,
                               const void* conv_out, const void* out, const float* mean, const float* rstd,
-                              void* dconv_ws, void* dx, float* dw, float* dbias, float* dgamma, float* dbeta,
+                              void* dconv_ws, void* col_ws, int64_t col_ws_bytes, void* dx, float* dw, float* dbias,
+                              float* dgamma, float* dbeta,
                               int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                               int kh, int kw, int sh, int sw, int dtype, void* stream);
 int neurst_maxpool3x3_fwd(const void* x, void* out, int8_t* argidx, int64_t B, int64_t H, int64_t W, int64_t C,

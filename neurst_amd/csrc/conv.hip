@@ -2,15 +2,11 @@
 // st/models/encoders/transformer_encoder.py:18-32,69-103 (tf.layers.conv2d, NHWC,
 // kernel [kh,kw,Cin,Cout]).  Small-K convolution: one wavefront per output pixel with the
 // output channels across the lanes, LN statistics by wavefront reduction, fused epilogue.
-#include "common.h"
+#include "conv.h"
 
 #define LN_EPS 1e-6f
 #define MAX_NCO 4  // Cout <= 256
 
-struct ConvGeom {
-  int64_t B, H, W, Cin, Cout, Ho, Wo;
-  int kh, kw, sh, sw, pt, pl;
-};
 static inline void same_pad(int64_t n, int k, int s, int64_t& out, int& before) {
   out = (n + s - 1) / s;
   int64_t total = (out - 1) * s + k - n;
@@ -175,6 +171,16 @@ static int make_geom(ConvGeom& g, int64_t B, int64_t H, int64_t W, int64_t Cin, 
 }
 static inline int pix_grid(int64_t npix) { int64_t x = cdiv64(npix, 4); return (int)(x > 4096 ? 4096 : (x < 1 ? 1 : x)); }
 
+int g_opt_conv_fast = 1;                     // neurst_set_option("conv_fast", 0): general kernels only (A/B tests)
+
+extern "C" int64_t neurst_conv2d_bwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kh, int kw, int sh,
+                                                     int sw, int dtype) {
+  ConvGeom g;
+  if (dtype != NEURST_BF16 || make_geom(g, B, H, W, Cin, Cout, kh, kw, sh, sw) != NEURST_OK) return 0;
+  if (kh * kw * Cin <= 32 && Cout <= 64) return 0;      // first-layer kernel: no im2col image
+  return neurst_conv_col_bytes(g);
+}
+
 extern "C" int neurst_conv2d_ln_relu_fwd(const void* x, const float* w, const float* bias, const float* gamma, const float* beta,
                                          void* conv_out, void* out, float* mean, float* rstd, int64_t B, int64_t H, int64_t W,
                                          int64_t Cin, int64_t Cout, int kh, int kw, int sh, int sw, int dtype, void* stream) {
@@ -182,6 +188,11 @@ extern "C" int neurst_conv2d_ln_relu_fwd(const void* x, const float* w, const fl
   int rc = make_geom(g, B, H, W, Cin, Cout, kh, kw, sh, sw);
   if (rc) return rc;
   int grid = pix_grid(g.B * g.Ho * g.Wo);
+  if (dtype == NEURST_BF16 && g_opt_conv_fast &&
+      neurst_conv_fwd_fast((const bf16_t*)x, w, bias, gamma, beta, (bf16_t*)conv_out, (bf16_t*)out, mean, rstd, g, as_stream(stream))) {
+    NEURST_CHECK_LAUNCH("conv2d_ln_relu_fwd(fast)");
+    return NEURST_OK;
+  }
   if (dtype == NEURST_BF16)
     conv_ln_relu_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, w, bias, gamma, beta, (bf16_t*)conv_out, (bf16_t*)out, mean, rstd, g);
   else
@@ -191,14 +202,35 @@ extern "C" int neurst_conv2d_ln_relu_fwd(const void* x, const float* w, const fl
 }
 
 extern "C" int neurst_conv2d_ln_relu_bwd(const void* dout, const void* x, const float* w, const float* gamma, const void* conv_out,
-                                         const void* out, const float* mean, const float* rstd, void* dconv_ws, void* dx, float* dw,
-                                         float* dbias, float* dgamma, float* dbeta, int64_t B, int64_t H, int64_t W, int64_t Cin,
-                                         int64_t Cout, int kh, int kw, int sh, int sw, int dtype, void* stream) {
+                                         const void* out, const float* mean, const float* rstd, void* dconv_ws, void* col_ws,
+                                         int64_t col_ws_bytes, void* dx, float* dw, float* dbias, float* dgamma, float* dbeta, int64_t B,
+                                         int64_t H, int64_t W, int64_t Cin, int64_t Cout, int kh, int kw, int sh, int sw, int dtype,
+                                         void* stream) {
   ConvGeom g;
   int rc = make_geom(g, B, H, W, Cin, Cout, kh, kw, sh, sw);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
   const int64_t npix = g.B * g.Ho * g.Wo;
+  if (dtype == NEURST_BF16 && g_opt_conv_fast) {
+    // every step falls back to its general kernel on its own when the shape is not one the fast path handles
+    const bf16_t* xb = (const bf16_t*)x;
+    bf16_t* dc = (bf16_t*)dconv_ws;
+    int grid1 = pix_grid(npix);
+    if (grid1 > 1024) grid1 = 1024;
+    if (!neurst_conv_bwd_pix_fast((const bf16_t*)dout, (const bf16_t*)conv_out, (const bf16_t*)out, gamma, mean, rstd, dc, dgamma, dbeta, dbias, g, s))
+      conv_ln_relu_bwd_pix_kernel<bf16_t><<<grid1, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)conv_out, (const bf16_t*)out, gamma, mean, rstd, dc, dgamma, dbeta, dbias, g);
+    if (!neurst_conv_dw_fast(xb, dc, dw, col_ws, col_ws_bytes, g, s)) {
+      int64_t ns = cdiv64(npix, 2048);
+      if (ns > 64) ns = 64;
+      conv_dw_kernel<bf16_t><<<dim3((unsigned)(kh * kw * Cin), (unsigned)ns), 256, 0, s>>>(xb, dc, dw, g);
+    }
+    if (dx && !neurst_conv_dx_fast(dc, w, (bf16_t*)dx, g, s)) {
+      const int64_t nd = B * H * W * Cin;
+      conv_dx_kernel<bf16_t><<<(int)(cdiv64(nd, 256) > 8192 ? 8192 : cdiv64(nd, 256)), 256, 0, s>>>(dc, w, (bf16_t*)dx, g);
+    }
+    NEURST_CHECK_LAUNCH("conv2d_ln_relu_bwd(fast)");
+    return NEURST_OK;
+  }
   int grid = pix_grid(npix);
   if (grid > 1024) grid = 1024;
   int64_t nsplit = cdiv64(npix, 2048);

@@ -643,12 +643,14 @@ int g_opt_gemm256_ablate = 0;
 int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TILES"); return e ? atoi(e) : 128; }();
 static bool use_gemm256() { return g_opt_gemm256 != 0; }
 int neurst_attention2_set_option(const char* name, int value);
+extern int g_opt_conv_fast;                                  // conv.hip
 extern "C" int neurst_set_option(const char* name, int value) {
   NEURST_CHECK_ARG(name, "set_option: null name");
   if (!strcmp(name, "gemm256")) g_opt_gemm256 = value;
   else if (!strcmp(name, "gemm256_min_tiles")) g_opt_gemm256_min_tiles = value;
   else if (!strcmp(name, "gemm256_bn")) g_opt_gemm256_bn = value;
   else if (!strcmp(name, "gemm256_ablate")) g_opt_gemm256_ablate = value;
+  else if (!strcmp(name, "conv_fast")) g_opt_conv_fast = value;
   else if (neurst_attention2_set_option(name, value)) {}
   else { neurst_set_error("set_option: unknown option '%s'", name); return NEURST_E_INVALID; }
   return NEURST_OK;

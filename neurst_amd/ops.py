@@ -58,6 +58,11 @@ def set_stream(stream):
     _override_raw = 0 if stream is None else stream.cuda_stream
 
 
+def set_option(name, value):
+    """Kernel-selection switch of the library (neurst_set_option: tests and A/B timing)."""
+    _chk(_C.neurst_set_option(name.encode(), int(value)), 'set_option(%s)' % name)
+
+
 def active_stream():
     return _override_stream if _override_stream is not None else torch.cuda.current_stream()
 
@@ -471,9 +476,11 @@ def conv2d_ln_relu_bwd(dout, x, w, gamma, conv_out, out, mean, rstd, dw, dbias, 
     Cout = w.shape[-1]
     ws = torch.empty_like(conv_out)
     dx = torch.empty_like(x) if need_dx else None
-    _chk(_C.neurst_conv2d_ln_relu_bwd(_p(_c(dout)), _p(x), _p(w), _p(gamma), _p(conv_out), _p(out), _p(mean), _p(rstd), _p(ws), _p(dx), _p(dw),
-                                       _p(dbias), _p(dgamma), _p(dbeta), B, H, W, Cin, Cout, kernel[0], kernel[1], stride[0], stride[1],
-                                       dt_of(x), _s()), 'conv2d_ln_relu_bwd')
+    nb = int(_C.neurst_conv2d_bwd_workspace_bytes(B, H, W, Cin, Cout, kernel[0], kernel[1], stride[0], stride[1], dt_of(x)))
+    col = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb > 0 else None      # im2col image for the weight-gradient GEMM
+    _chk(_C.neurst_conv2d_ln_relu_bwd(_p(_c(dout)), _p(x), _p(w), _p(gamma), _p(conv_out), _p(out), _p(mean), _p(rstd), _p(ws), _p(col), nb,
+                                       _p(dx), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), B, H, W, Cin, Cout, kernel[0], kernel[1], stride[0],
+                                       stride[1], dt_of(x), _s()), 'conv2d_ln_relu_bwd')
     return dx
 
 

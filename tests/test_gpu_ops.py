@@ -635,6 +635,68 @@ def test_conv_ln_relu_and_maxpool():
         assert relerr(host(got), want) < 2e-5
 
 
+@pytest.mark.parametrize('H,W,Cin,Cout,stride', [(13, 10, 64, 64, (2, 2)), (9, 12, 32, 64, (2, 2)), (11, 7, 64, 32, (1, 1)), (10, 9, 32, 32, (2, 1)),
+                                                 (13, 10, 1, 64, (2, 2)), (12, 11, 3, 64, (2, 2)), (7, 9, 3, 40, (1, 2))])
+def test_conv_bf16_fast_paths_against_oracle(H, W, Cin, Cout, stride):
+    """bf16 layers: implicit-GEMM MFMA kernels (3x3, Cin % 32 == 0: forward and data gradient), im2col + GEMM weight gradient,
+    the registers-resident first-layer kernels (kh kw Cin <= 32) and the 16-byte-lane LN backward, against the oracle on operands
+    that bf16 holds exactly; the oracle rounds where the kernels store bf16 (conv_out, dconv)."""
+    rng = np.random.default_rng(100 + Cin + Cout)
+    B = 3
+    x = bf16_round(rng.standard_normal((B, H, W, Cin)))
+    w = bf16_round(rng.standard_normal((3, 3, Cin, Cout)) * (0.3 / np.sqrt(Cin)))
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    c, ccache = O.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b, stride)
+    c = bf16_round(c).astype(np.float64)
+    l, lcache = O.layer_norm_fwd(c, gam.astype(np.float64), bet)
+    r = np.maximum(l, 0)
+    bf = lambda a: dev(a).to(torch.bfloat16)
+    out, conv_out, mean, rstd = ops.conv2d_ln_relu_fwd(bf(x), dev(w), dev(b), dev(gam), dev(bet), (3, 3), stride)
+    assert relerr(host(conv_out.float()), c) < 1e-2          # one bf16 rounding where a sum lands next to a tie
+    assert relerr(host(out.float()), r) < 2e-2
+    assert relerr(host(mean), c.mean(-1).reshape(-1)) < 1e-2
+    dr = bf16_round(rng.standard_normal(r.shape))
+    outk = host(out.float())
+    dl, dg_ref, db_ref = O.layer_norm_bwd(dr * (outk > 0), lcache, gam.astype(np.float64))      # gate as the kernel sees it (stored out > 0)
+    dlr = bf16_round(dl).astype(np.float64)
+    dx_ref, dw_ref, dbias_ref = O.conv2d_bwd(dlr, ccache, w.astype(np.float64), stride, x.shape)
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)
+    dw, dbias, dg, db = z(3, 3, Cin, Cout), z(Cout), z(Cout), z(Cout)
+    dx = ops.conv2d_ln_relu_bwd(bf(dr), bf(x), dev(w), dev(gam), conv_out, out, mean, rstd, dw, dbias, dg, db, (3, 3), stride, True)
+    for name, got, want, tol in [('dx', dx.float(), dx_ref, 2e-2), ('dw', dw, dw_ref, 2e-2), ('dbias', dbias, dbias_ref, 2e-2),
+                                 ('dgamma', dg, dg_ref, 2e-2), ('dbeta', db, db_ref, 2e-2)]:
+        assert relerr(host(got), want) < tol, name
+
+
+def test_conv_fast_paths_agree_with_the_general_kernels():
+    """Same bf16 inputs through the fast paths and, with the option off, through the general kernels (fp32 FMA chains over the same
+    bf16 operands): conv_out may differ by one bf16 rounding in rare elements, gradients by accumulation order."""
+    rng = np.random.default_rng(7)
+    B, H, W, Cin, Cout = 4, 150, 40, 64, 64
+    bf = lambda a: dev(a).to(torch.bfloat16)
+    x = bf(rng.standard_normal((B, H, W, Cin)))
+    w = dev(bf16_round(rng.standard_normal((3, 3, Cin, Cout)) * 0.04))
+    b, gam, bet = dev(rng.standard_normal(Cout) * 0.1), dev(1 + 0.1 * rng.standard_normal(Cout)), dev(0.1 * rng.standard_normal(Cout))
+    dr = bf(rng.standard_normal((B, H // 2, W // 2, Cout)))
+    res = []
+    for fast in (1, 0):
+        ops.set_option('conv_fast', fast)
+        try:
+            out, conv_out, mean, rstd = ops.conv2d_ln_relu_fwd(x, w, b, gam, bet, (3, 3), (2, 2))
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=DEV)
+            dw, dbias, dg, db = z(3, 3, Cin, Cout), z(Cout), z(Cout), z(Cout)
+            dx = ops.conv2d_ln_relu_bwd(dr, x, w, gam, conv_out, out, mean, rstd, dw, dbias, dg, db, (3, 3), (2, 2), True)
+            res.append([host(t.float()) for t in (conv_out, out, dx, dw, dbias, dg, db)])
+        finally:
+            ops.set_option('conv_fast', 1)
+    names = ('conv_out', 'out', 'dx', 'dw', 'dbias', 'dgamma', 'dbeta')
+    for n, a, g_ in zip(names, res[0], res[1]):
+        assert relerr(a, g_) < (1e-2 if n in ('conv_out', 'out', 'dx') else 2e-3), n
+    assert (res[0][0] != res[1][0]).mean() < 1e-3            # conv_out: bit-equal but for rare rounding flips
+
+
 def test_adam_matches_tf_formula():
     rng = np.random.default_rng(13)
     n = 1003

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel-level timing (HIP events, interleaved rounds in one process) of the GEMM / attention / LN shapes
-of the LUT step.  Usage: python tools/bench_kernels.py [gemm|attn|ln|all]"""
+of the LUT step.  Usage: python tools/bench_kernels.py [gemm|attn|ln|conv|all]"""
 import os
 import sys
 
@@ -122,6 +122,36 @@ def bench_ln():
         print('ln bwd rate=%.1f %7.1f us  %6.0f GB/s (%d*rows*C*2 B)' % (rate, m, (4 if rate else 3) * rows * C * 2 / m / 1e3, 4 if rate else 3))
 
 
+def bench_conv():
+    """a4: the two conv + LN + ReLU layers of a `use_cnn_resample` front end at BASELINE config 2's input (32 x 1500 x 80),
+    3 x 3 kernels, stride 2, 64 filters (transformer_encoder.py:69-95), and the 3 x 3 max pool behind them.  Algorithmic
+    bytes: forward reads x and writes conv_out + out; backward reads dout, conv_out, out, x and writes dx."""
+    B = int(os.environ.get('CONV_B', '32'))
+    for name, H, W, Cin, Cout, need_dx in (('conv_0', 1500, 80, int(os.environ.get('CONV_CIN', '1')), 64, False), ('conv_1', 750, 40, 64, 64, True)):
+        x = torch.randn(B, H, W, Cin, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(3, 3, Cin, Cout, device=DEV) * 0.1)
+        bias, gam, bet = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+        f = lambda: ops.conv2d_ln_relu_fwd(x, w, bias, gam, bet, (3, 3), (2, 2))
+        out, conv_out, mean, rstd = f()
+        m, _ = timeit(f, reps=10)
+        nb = (x.numel() + 2 * out.numel()) * 2
+        fl = 2.0 * out.numel() * 9 * Cin
+        print('%s fwd  [%d,%d,%d,%d]->%d  %8.1f us  %6.0f GB/s  %6.1f TF/s' % (name, B, H, W, Cin, Cout, m, nb / m / 1e3, fl / m / 1e6))
+        dout = torch.randn_like(out)
+        dw, db, dg, dbe = torch.zeros_like(w), torch.zeros(Cout, device=DEV), torch.zeros(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+        f2 = lambda: ops.conv2d_ln_relu_bwd(dout, x, w, gam, conv_out, out, mean, rstd, dw, db, dg, dbe, (3, 3), (2, 2), need_dx)
+        m, _ = timeit(f2, reps=5)
+        nb = (3 * out.numel() + x.numel() * (2 if need_dx else 1)) * 2
+        print('%s bwd  (dx %s)             %8.1f us  %6.0f GB/s  %6.1f TF/s' % (name, need_dx, m, nb / m / 1e3, fl * (2 if need_dx else 1) / m / 1e6))
+    y = torch.randn(B, 375, 20, 64, device=DEV).to(torch.bfloat16)
+    f3 = lambda: ops.maxpool3x3_fwd(y)
+    m, _ = timeit(f3)
+    print('maxpool fwd [%d,375,20,64]       %8.1f us  %6.0f GB/s' % (B, m, y.numel() * 5 / m / 1e3))
+    o, arg = f3()
+    m, _ = timeit(lambda: ops.maxpool3x3_bwd(o, arg))
+    print('maxpool bwd                      %8.1f us  %6.0f GB/s' % (m, y.numel() * 5 / m / 1e3))
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what == 'wgrad':
@@ -132,3 +162,5 @@ if __name__ == '__main__':
         bench_attn()
     if what in ('ln', 'all'):
         bench_ln()
+    if what in ('conv', 'all'):
+        bench_conv()
