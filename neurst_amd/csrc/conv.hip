@@ -282,11 +282,71 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dout, const int8_t* __r
     dx[idx] = from_f32<T>(s);
   }
 }
+// bf16, C % 8 == 0: 8 channels (16 bytes) per thread
+__global__ void __launch_bounds__(256) maxpool_fwd_vec_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int8_t* __restrict__ arg,
+                                                              int64_t B, int64_t H, int64_t W, int64_t C) {
+  const int64_t c8n = C / 8, total = B * H * W * c8n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c8 = idx % c8n, r = idx / c8n, wi = r % W, r2 = r / W, hi = r2 % H, b = r2 / H;
+    float best[8];
+    int bk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bk[e] = 4; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int64_t h2 = hi + k / 3 - 1, w2 = wi + k % 3 - 1;
+      if (h2 < 0 || h2 >= H || w2 < 0 || w2 >= W) continue;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((b * H + h2) * W + w2) * C + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((float)v[e] > best[e]) { best[e] = (float)v[e]; bk[e] = k; }
+    }
+    bf16x8 o;
+    unsigned lo = 0, hi4 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo |= (unsigned)bk[e] << (8 * e); hi4 |= (unsigned)bk[4 + e] << (8 * e); }
+    *reinterpret_cast<bf16x8*>(out + r * C + c8 * 8) = o;
+    *reinterpret_cast<u32x2*>(arg + r * C + c8 * 8) = u32x2{lo, hi4};
+  }
+}
+__global__ void __launch_bounds__(256) maxpool_bwd_vec_kernel(const bf16_t* __restrict__ dout, const int8_t* __restrict__ arg,
+                                                              bf16_t* __restrict__ dx, int64_t B, int64_t H, int64_t W, int64_t C) {
+  const int64_t c8n = C / 8, total = B * H * W * c8n;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c8 = idx % c8n, r = idx / c8n, wi = r % W, r2 = r / W, hi = r2 % H, b = r2 / H;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {   // output (h2,w2) picked this input iff its argmax tap points back here
+      const int64_t h2 = hi - (k / 3 - 1), w2 = wi - (k % 3 - 1);
+      if (h2 < 0 || h2 >= H || w2 < 0 || w2 >= W) continue;
+      const int64_t o = ((b * H + h2) * W + w2) * C + c8 * 8;
+      const u32x2 a = *reinterpret_cast<const u32x2*>(arg + o);
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((int)(((e < 4 ? a[0] : a[1]) >> (8 * (e & 3))) & 0xff) == k) s[e] += (float)d[e];
+    }
+    bf16x8 o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)s[e];
+    *reinterpret_cast<bf16x8*>(dx + r * C + c8 * 8) = o8;
+  }
+}
+static inline bool pool_vec_ok(const void* a, const void* b, const void* c, int64_t C) {
+  return C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && (((uintptr_t)c) & 7) == 0;
+}
 extern "C" int neurst_maxpool3x3_fwd(const void* x, void* out, int8_t* argidx, int64_t B, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
   NEURST_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0, "maxpool: bad shape");
   int64_t n = B * H * W * C;
   int grid = (int)(cdiv64(n, 256) > 8192 ? 8192 : cdiv64(n, 256));
-  if (dtype == NEURST_BF16) maxpool_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, (bf16_t*)out, argidx, B, H, W, C);
+  if (dtype == NEURST_BF16 && pool_vec_ok(x, out, argidx, C)) {
+    const int64_t n8 = n / 8;
+    maxpool_fwd_vec_kernel<<<(int)(cdiv64(n8, 256) > 8192 ? 8192 : cdiv64(n8, 256)), 256, 0, as_stream(stream)>>>((const bf16_t*)x, (bf16_t*)out, argidx, B, H, W, C);
+  } else if (dtype == NEURST_BF16) maxpool_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, (bf16_t*)out, argidx, B, H, W, C);
   else maxpool_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)x, (float*)out, argidx, B, H, W, C);
   NEURST_CHECK_LAUNCH("maxpool3x3_fwd");
   return NEURST_OK;
@@ -295,7 +355,10 @@ extern "C" int neurst_maxpool3x3_bwd(const void* dout, const int8_t* argidx, voi
   NEURST_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0, "maxpool: bad shape");
   int64_t n = B * H * W * C;
   int grid = (int)(cdiv64(n, 256) > 8192 ? 8192 : cdiv64(n, 256));
-  if (dtype == NEURST_BF16) maxpool_bwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)dout, argidx, (bf16_t*)dx, B, H, W, C);
+  if (dtype == NEURST_BF16 && pool_vec_ok(dout, dx, argidx, C)) {
+    const int64_t n8 = n / 8;
+    maxpool_bwd_vec_kernel<<<(int)(cdiv64(n8, 256) > 8192 ? 8192 : cdiv64(n8, 256)), 256, 0, as_stream(stream)>>>((const bf16_t*)dout, argidx, (bf16_t*)dx, B, H, W, C);
+  } else if (dtype == NEURST_BF16) maxpool_bwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)dout, argidx, (bf16_t*)dx, B, H, W, C);
   else maxpool_bwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)dout, argidx, (float*)dx, B, H, W, C);
   NEURST_CHECK_LAUNCH("maxpool3x3_bwd");
   return NEURST_OK;

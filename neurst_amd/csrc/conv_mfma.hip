@@ -32,19 +32,22 @@ namespace cv {
 
 constexpr int NTH = 512, NWV = 8, PADK = 8;
 
-template <int NJ, int NC, bool DX>
+template <int NJ, int NC, bool DX, bool GATHER = false>
 constexpr size_t mfma_lds_bytes() {
-  return (size_t)(16 * NJ) * (9 * 32 * NC + PADK) * 2 + (size_t)NWV * 16 * (16 * NJ + 4) * 4 + 3 * 16 * NJ * 4;
+  return (size_t)(16 * NJ) * ((GATHER ? 32 : 9 * 32 * NC) + PADK) * 2 + (size_t)NWV * 16 * (16 * NJ + 4) * 4 + 3 * 16 * NJ * 4;
 }
 
 // NJ = 16-column MFMA tiles of the output (N = 16 NJ channels), NC = 32-element chunks of the reduction channels (C = 32 NC)
-template <int NJ, int NC, bool DX>
+// GATHER (forward only): a layer with at most 32 reduction elements in all (kh kw Cin <= 32: the first layer, Cin = 1 .. 3) as
+// ONE K-step - every lane gathers its 8 reduction elements (tap, ci) with 2-byte loads, the weight image is zero beyond K.
+template <int NJ, int NC, bool DX, bool GATHER = false>
 __global__ void __launch_bounds__(NTH) conv3x3_mfma_kernel(const bf16_t* __restrict__ src, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16_t* __restrict__ dst0,
                                                            bf16_t* __restrict__ dst1, float* __restrict__ mean, float* __restrict__ rstd,
                                                            ConvGeom g) {
-  constexpr int N = 16 * NJ, C = 32 * NC, K = 9 * C, LDW = K + PADK, LDC = N + 4, CW = 4 * NJ;
+  constexpr int N = 16 * NJ, C = 32 * NC, NS = GATHER ? 1 : 9 * NC, K = 32 * NS, LDW = K + PADK, LDC = N + 4, CW = 4 * NJ;
+  static_assert(!(GATHER && DX), "the gathering variant is a forward kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* const wl = reinterpret_cast<bf16_t*>(smem);                                 // [N][LDW]: row n, reduction index contiguous
   float* const stage = reinterpret_cast<float*>(smem + (size_t)N * LDW * 2);          // [NWV][16][LDC]
@@ -52,11 +55,18 @@ __global__ void __launch_bounds__(NTH) conv3x3_mfma_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Cin = (int)g.Cin, Cout = (int)g.Cout;
-  for (int idx = tid; idx < 9 * Cin * Cout; idx += NTH) {                            // global layout [tap][ci][co]
-    const int co = idx % Cout, r = idx / Cout, ci = r % Cin, tap = r / Cin;
-    const bf16_t v = (bf16_t)w[idx];
-    if constexpr (!DX) wl[co * LDW + tap * C + ci] = v;
-    else wl[ci * LDW + tap * C + co] = v;
+  const int Kt = g.kh * g.kw * Cin;                                                   // reduction elements in all
+  if constexpr (GATHER) {
+    for (int idx = tid; idx < N * LDW; idx += NTH) wl[idx] = (bf16_t)0.f;
+    __syncthreads();
+    for (int idx = tid; idx < Kt * Cout; idx += NTH) wl[(idx % Cout) * LDW + idx / Cout] = (bf16_t)w[idx];   // [k][co] -> [co][k]
+  } else {
+    for (int idx = tid; idx < 9 * Cin * Cout; idx += NTH) {                          // global layout [tap][ci][co]
+      const int co = idx % Cout, r = idx / Cout, ci = r % Cin, tap = r / Cin;
+      const bf16_t v = (bf16_t)w[idx];
+      if constexpr (!DX) wl[co * LDW + tap * C + ci] = v;
+      else wl[ci * LDW + tap * C + co] = v;
+    }
   }
   if constexpr (!DX) {
     for (int i = tid; i < N; i += NTH) { par[i] = bias[i]; par[N + i] = gamma[i]; par[2 * N + i] = beta[i]; }
@@ -67,11 +77,31 @@ __global__ void __launch_bounds__(NTH) conv3x3_mfma_kernel(const bf16_t* __restr
   const int r16 = lane & 15, kg = lane >> 4;
   float* const Cs = stage + wave * 16 * LDC;
   const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  // GATHER: this lane's reduction elements k = 8 kg + e as (tap row i, tap column j, offset from the pixel's first input element)
+  int gi[8], gj[8], goff[8];
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kg * 8 + e, tap = k / Cin, ci = k - tap * Cin;
+      gi[e] = k < Kt ? tap / g.kw : -(1 << 20);                                    // beyond K: never inside the image
+      gj[e] = tap % g.kw;
+      goff[e] = ((tap / g.kw) * (int)g.W + gj[e]) * Cin + ci;
+    }
+  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p = tile * (16 * NWV) + wave * 16 + r16;
     const bool pv = p < M;
-    bf16x8 a[9 * NC];
-    if constexpr (!DX) {
+    bf16x8 a[NS];
+    if constexpr (GATHER) {
+      const int64_t wo = p % g.Wo, t = p / g.Wo, ho = t % g.Ho, b = t / g.Ho;
+      const int h0 = (int)ho * g.sh - g.pt, w0 = (int)wo * g.sw - g.pl;
+      const int64_t base = ((b * g.H + h0) * g.W + w0) * Cin;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = pv && (unsigned)(h0 + gi[e]) < (unsigned)g.H && (unsigned)(w0 + gj[e]) < (unsigned)g.W;
+        a[0][e] = ok ? src[base + goff[e]] : (bf16_t)0.f;
+      }
+    } else if constexpr (!DX) {
       const int64_t wo = p % g.Wo, t = p / g.Wo, ho = t % g.Ho, b = t / g.Ho;
       const int h0 = (int)ho * g.sh - g.pt, w0 = (int)wo * g.sw - g.pl;
       const int64_t base = ((b * g.H + h0) * g.W + w0) * Cin + kg * 8;
@@ -107,7 +137,7 @@ __global__ void __launch_bounds__(NTH) conv3x3_mfma_kernel(const bf16_t* __restr
 #pragma unroll
     for (int jn = 0; jn < NJ; ++jn) acc[jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 9 * NC; ++s)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int jn = 0; jn < NJ; ++jn) {
         const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(wl + (jn * 16 + r16) * LDW + s * 32 + kg * 8);
@@ -167,12 +197,32 @@ __device__ __forceinline__ float lane_bcast(float v, int k) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
 }
 
-// input element that reduction index `lane` (= tap * Cin + ci) of output pixel `pix` reads, or 0 outside the image / beyond K
-__device__ __forceinline__ float patch_elem(const bf16_t* __restrict__ x, const ConvGeom& g, int64_t pix, bool kvalid, int ti, int tj, int tci) {
-  const int64_t wo = pix % g.Wo, t = pix / g.Wo, ho = t % g.Ho, b = t / g.Ho;
-  const int64_t hi = ho * g.sh + ti - g.pt, wi = wo * g.sw + tj - g.pl;
-  const bool ok = kvalid && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
-  return ok ? (float)x[((b * g.H + hi) * g.W + wi) * g.Cin + tci] : 0.f;
+// (b, ho, wo) of an output pixel; 32-bit division when the pixel count allows (wave-uniform operands: scalar unit)
+struct PixPos { int b, ho, wo; };
+__device__ __forceinline__ PixPos pix_pos(const ConvGeom& g, int64_t pix, bool small) {
+  PixPos r;
+  if (small) {
+    const unsigned p = (unsigned)pix, Wo = (unsigned)g.Wo, Ho = (unsigned)g.Ho;
+    const unsigned t = p / Wo;
+    r.wo = (int)(p - t * Wo);
+    r.b = (int)(t / Ho);
+    r.ho = (int)(t - (unsigned)r.b * Ho);
+  } else {
+    const int64_t t = pix / g.Wo;
+    r.wo = (int)(pix % g.Wo);
+    r.ho = (int)(t % g.Ho);
+    r.b = (int)(t / g.Ho);
+  }
+  return r;
+}
+__device__ __forceinline__ void pix_next(const ConvGeom& g, PixPos& r) {
+  if (++r.wo == (int)g.Wo) { r.wo = 0; if (++r.ho == (int)g.Ho) { r.ho = 0; ++r.b; } }
+}
+// input element that reduction index `lane` (= tap * Cin + ci) of the output pixel at `r` reads, or 0 outside the image / beyond K
+__device__ __forceinline__ float patch_elem(const bf16_t* __restrict__ x, const ConvGeom& g, const PixPos& r, bool kvalid, int ti, int tj, int tci) {
+  const int hi = r.ho * g.sh + ti - g.pt, wi = r.wo * g.sw + tj - g.pl;
+  const bool ok = kvalid && hi >= 0 && hi < (int)g.H && wi >= 0 && wi < (int)g.W;
+  return ok ? (float)x[(((int64_t)r.b * g.H + hi) * g.W + wi) * g.Cin + tci] : 0.f;
 }
 
 // first layer: K = kh kw Cin <= KM <= 32 reduction elements, Cout <= 64; lane = output channel, weights in registers
@@ -195,10 +245,17 @@ __global__ void __launch_bounds__(256) conv_smallk_fwd_kernel(const bf16_t* __re
   const int64_t npix = g.B * g.Ho * g.Wo;
   const float invC = 1.f / (float)Cout;
   constexpr int PP = 4;
+  __shared__ __attribute__((aligned(16))) bf16_t st[4][2][PP][64];   // per wave: 4 pixel rows of conv_out and of out
+  const bool small = npix < (1ll << 31);
   for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PP; p0 < npix; p0 += (int64_t)gridDim.x * 4 * PP) {
     float xv[PP];
+    PixPos pos = pix_pos(g, p0, small);
 #pragma unroll
-    for (int q = 0; q < PP; ++q) xv[q] = (p0 + q < npix) ? patch_elem(x, g, p0 + q, kvalid, ti, tj, tci) : 0.f;
+    for (int q = 0; q < PP; ++q) {
+      xv[q] = (p0 + q < npix) ? patch_elem(x, g, pos, kvalid, ti, tj, tci) : 0.f;
+      pix_next(g, pos);
+    }
+    const bool packed = Cout == 64 && p0 + PP <= npix;       // 4 whole pixel rows = 512 contiguous bytes per tensor
 #pragma unroll
     for (int q = 0; q < PP; ++q) {
       const int64_t pix = p0 + q;
@@ -207,23 +264,35 @@ __global__ void __launch_bounds__(256) conv_smallk_fwd_kernel(const bf16_t* __re
 #pragma unroll
       for (int k = 0; k < KM; ++k) acc = fmaf(lane_bcast(xv[q], k), wr[k], acc);
       acc = (float)(bf16_t)acc;
-      const float mu = wave_sum(cvd ? acc : 0.f) * invC;
+      const float mu = wave_sum_dpp(cvd ? acc : 0.f) * invC;
       const float d = cvd ? acc - mu : 0.f;
-      const float rs = 1.0f / sqrtf(wave_sum(d * d) * invC + LN_EPS);
-      if (cvd) {
+      const float rs = 1.0f / sqrtf(wave_sum_dpp(d * d) * invC + LN_EPS);
+      const bf16_t o = (bf16_t)fmaxf((d * rs) * gm + bt, 0.f);
+      if (packed) {
+        st[wv][0][q][lane] = (bf16_t)acc;
+        st[wv][1][q][lane] = o;
+      } else if (cvd) {
         conv_out[pix * Cout + lane] = (bf16_t)acc;
-        out[pix * Cout + lane] = (bf16_t)fmaxf((d * rs) * gm + bt, 0.f);
+        out[pix * Cout + lane] = o;
       }
       if (lane == 0) { mean[pix] = mu; rstd[pix] = rs; }
+    }
+    if (packed) {   // the same wave reads back what it wrote (LDS operations of one wave complete in order): 8 bytes per lane
+      const u32x2 c2 = *reinterpret_cast<const u32x2*>(&st[wv][0][0][0] + lane * 4);
+      const u32x2 o2 = *reinterpret_cast<const u32x2*>(&st[wv][1][0][0] + lane * 4);
+      *reinterpret_cast<u32x2*>(conv_out + p0 * 64 + lane * 4) = c2;
+      *reinterpret_cast<u32x2*>(out + p0 * 64 + lane * 4) = o2;
     }
   }
 }
 
 // weight gradient of the first layer: dw[k][co] += sum_pix patch[pix][k] * dconv[pix][co]; lane = output channel, KM accumulators
 template <int KM>
-__global__ void __launch_bounds__(256) conv_smallk_dw_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dconv,
+__global__ void __launch_bounds__(1024) conv_smallk_dw_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dconv,
                                                              float* __restrict__ dw, ConvGeom g, int K) {
-  __shared__ float red[4][KM][64];
+  constexpr int NWD = 16;                                      // waves per workgroup: one set of atomics per 16 waves
+  extern __shared__ __attribute__((aligned(16))) char smem_dw[];
+  float (*red)[KM][64] = reinterpret_cast<float (*)[KM][64]>(smem_dw);   // [NWD][KM][64]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Cout = (int)g.Cout;
@@ -234,14 +303,17 @@ __global__ void __launch_bounds__(256) conv_smallk_dw_kernel(const bf16_t* __res
   float acc[KM];
 #pragma unroll
   for (int k = 0; k < KM; ++k) acc[k] = 0.f;
-  constexpr int PP = 4;
-  for (int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * PP; p0 < npix; p0 += (int64_t)gridDim.x * 4 * PP) {
+  constexpr int PP = 8;
+  const bool small = npix < (1ll << 31);
+  for (int64_t p0 = ((int64_t)blockIdx.x * NWD + wv) * PP; p0 < npix; p0 += (int64_t)gridDim.x * NWD * PP) {
     float xv[PP], dv[PP];
+    PixPos pos = pix_pos(g, p0, small);
 #pragma unroll
     for (int q = 0; q < PP; ++q) {
       const bool in = p0 + q < npix;
-      xv[q] = in ? patch_elem(x, g, p0 + q, kvalid, ti, tj, tci) : 0.f;
+      xv[q] = in ? patch_elem(x, g, pos, kvalid, ti, tj, tci) : 0.f;
       dv[q] = (in && cvd) ? (float)dconv[(p0 + q) * Cout + lane] : 0.f;
+      pix_next(g, pos);
     }
 #pragma unroll
     for (int q = 0; q < PP; ++q)
@@ -251,9 +323,12 @@ __global__ void __launch_bounds__(256) conv_smallk_dw_kernel(const bf16_t* __res
 #pragma unroll
   for (int k = 0; k < KM; ++k) red[wv][k][lane] = acc[k];
   __syncthreads();
-  for (int i = threadIdx.x; i < K * 64; i += 256) {
+  for (int i = threadIdx.x; i < K * 64; i += 64 * NWD) {
     const int k = i >> 6, co = i & 63;
-    if (co < Cout) atomicAdd(dw + (int64_t)k * Cout + co, red[0][k][co] + red[1][k][co] + red[2][k][co] + red[3][k][co]);
+    float t = 0.f;
+#pragma unroll
+    for (int v = 0; v < NWD; ++v) t += red[v][k][co];
+    if (co < Cout) atomicAdd(dw + (int64_t)k * Cout + co, t);
   }
 }
 
@@ -357,6 +432,15 @@ static bool launch_mfma(const bf16_t* src, const float* w, const float* bias, co
   conv3x3_mfma_kernel<NJ, NC, DX><<<grid, NTH, lds, s>>>(src, w, bias, gamma, beta, d0, d1, mean, rstd, g);
   return true;
 }
+template <int NJ>
+static bool launch_gather(const bf16_t* x, const float* w, const float* bias, const float* gamma, const float* beta, bf16_t* d0, bf16_t* d1,
+                          float* mean, float* rstd, const ConvGeom& g, hipStream_t s) {
+  constexpr size_t lds = mfma_lds_bytes<NJ, 1, false, true>();
+  const int64_t ntiles = cdiv64(g.B * g.Ho * g.Wo, 16 * NWV);
+  const int grid = (int)(ntiles < 1024 ? ntiles : 1024);       // 4 workgroups per CU: the kernel is all load latency and stores
+  conv3x3_mfma_kernel<NJ, 1, false, true><<<grid, NTH, lds, s>>>(x, w, bias, gamma, beta, d0, d1, mean, rstd, g);
+  return true;
+}
 template <bool DX>
 static bool dispatch_mfma(int n_ch, int red_ch, const bf16_t* src, const float* w, const float* bias, const float* gamma, const float* beta,
                           bf16_t* d0, bf16_t* d1, float* mean, float* rstd, const ConvGeom& g, hipStream_t s) {
@@ -377,6 +461,11 @@ bool neurst_conv_fwd_fast(const bf16_t* x, const float* w, const float* bias, co
       cv::dispatch_mfma<false>((int)g.Cout, (int)g.Cin, x, w, bias, gamma, beta, conv_out, out, mean, rstd, g, s))
     return true;
   const int K = g.kh * g.kw * (int)g.Cin;
+  if (K <= 32 && cv::aligned16(conv_out) && cv::aligned16(out) && (int64_t)g.kh * g.W * g.Cin < (1 << 30)) {
+    if (g.Cout == 64) return cv::launch_gather<4>(x, w, bias, gamma, beta, conv_out, out, mean, rstd, g, s);
+    if (g.Cout == 32) return cv::launch_gather<2>(x, w, bias, gamma, beta, conv_out, out, mean, rstd, g, s);
+    if (g.Cout == 128) return cv::launch_gather<8>(x, w, bias, gamma, beta, conv_out, out, mean, rstd, g, s);
+  }
   if (K <= 32 && g.Cout <= 64) {
     const int64_t npix = g.B * g.Ho * g.Wo;
     const int64_t want = cdiv64(npix, 16);
@@ -417,11 +506,16 @@ bool neurst_conv_dw_fast(const bf16_t* x, const bf16_t* dconv, float* dw, void* 
   const int K = g.kh * g.kw * (int)g.Cin;
   const int64_t npix = g.B * g.Ho * g.Wo;
   if (K <= 32 && g.Cout <= 64) {
-    const int64_t want = cdiv64(npix, 16 * 64);
-    const int grid = (int)(want > 256 ? 256 : (want < 1 ? 1 : want));
-    if (K <= 9) cv::conv_smallk_dw_kernel<9><<<grid, 256, 0, s>>>(x, dconv, dw, g, K);
-    else if (K <= 27) cv::conv_smallk_dw_kernel<27><<<grid, 256, 0, s>>>(x, dconv, dw, g, K);
-    else cv::conv_smallk_dw_kernel<32><<<grid, 256, 0, s>>>(x, dconv, dw, g, K);
+    const int64_t want = cdiv64(npix, 16 * 8 * 4);
+    const int grid = (int)(want > 512 ? 512 : (want < 1 ? 1 : want));
+#define CV_DW(km)                                                                                                          \
+  do {                                                                                                                       \
+    constexpr int lds = 16 * km * 64 * 4;                                                                                    \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(cv::conv_smallk_dw_kernel<km>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    cv::conv_smallk_dw_kernel<km><<<grid, 1024, lds, s>>>(x, dconv, dw, g, K);                                               \
+  } while (0)
+    if (K <= 9) CV_DW(9); else if (K <= 27) CV_DW(27); else CV_DW(32);
+#undef CV_DW
     return true;
   }
   const int64_t need = neurst_conv_col_bytes(g);

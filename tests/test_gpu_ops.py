@@ -670,6 +670,20 @@ def test_conv_bf16_fast_paths_against_oracle(H, W, Cin, Cout, stride):
         assert relerr(host(got), want) < tol, name
 
 
+def test_maxpool_bf16_vector_path():
+    """3x3 / stride-1 SAME max pool with 8 channels per thread (bf16, C % 8 == 0): values bit-exact (a maximum of stored
+    values), gradient = sum of up to 9 bf16 values rounded once."""
+    rng = np.random.default_rng(21)
+    x = bf16_round(rng.standard_normal((2, 7, 9, 24)))
+    pooled, parg = O.maxpool3x3_fwd(x.astype(np.float64))
+    po, arg = ops.maxpool3x3_fwd(dev(x).to(torch.bfloat16))
+    assert np.array_equal(host(po.float()), pooled.astype(np.float32))
+    dpo = bf16_round(rng.standard_normal(pooled.shape))
+    dr = O.maxpool3x3_bwd(dpo.astype(np.float64), parg)
+    dx = ops.maxpool3x3_bwd(dev(dpo).to(torch.bfloat16), arg)
+    assert relerr(host(dx.float()), dr) < 8e-3
+
+
 def test_conv_fast_paths_agree_with_the_general_kernels():
     """Same bf16 inputs through the fast paths and, with the option off, through the general kernels (fp32 FMA chains over the same
     bf16 operands): conv_out may differ by one bf16 rounding in rare elements, gradients by accumulation order."""
