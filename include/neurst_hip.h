@@ -313,6 +313,13 @@ int neurst_maxpool3x3_bwd(const void* dout, const int8_t* argidx, void* dx, int6
  * shadow (may be NULL) receives the bf16 copy of the updated parameters. */
 int neurst_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
                      float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* handle_gradients (st/tools/tftools/gradientTools.py:40-67), the two rules that reach this model's variables (the value and
+ * per-variable norm clips only touch variables named *lstm*): L2 penalty g += lambda * v on non-bias variables = axpy on
+ * the variable's slice of the gradient arena; tf.clip_by_global_norm needs sqrt(sum g^2) over all gradients: block partials
+ * (fp64, neurst_sumsq_blocks(n) of them) that the caller sums; the clip factor then rides on Adam's grad_scale. */
+int neurst_axpy_f32(float* y, const float* x, float alpha, int64_t n, void* stream);
+int64_t neurst_sumsq_blocks(int64_t n);
+int neurst_sumsq_f32(const float* x, int64_t n, void* partial_f64, void* stream);
 /* dtype conversion fp32 -> bf16 (parameter shadow after loading weights). */
 int neurst_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int neurst_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -345,6 +345,34 @@ __global__ void cast_f2b_kernel(const float* __restrict__ s, bf16_t* __restrict_
 __global__ void cast_b2f_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
 }
+// handle_gradients (st/tools/tftools/gradientTools.py:40-67): the L2 penalty is y += alpha x on a variable's slice of the
+// gradient arena, the global norm a sum of squares over the whole arena (block partials, summed by the caller in fp64)
+__global__ void axpy_f32_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = fmaf(alpha, x[i], y[i]);
+}
+extern "C" int neurst_axpy_f32(float* y, const float* x, float alpha, int64_t n, void* stream) {
+  NEURST_CHECK_ARG(y && x && n > 0, "axpy: bad args");
+  axpy_f32_kernel<<<grid_for(n, 256, 4), 256, 0, as_stream(stream)>>>(y, x, alpha, n);
+  NEURST_CHECK_LAUNCH("axpy_f32");
+  return NEURST_OK;
+}
+extern "C" int64_t neurst_sumsq_blocks(int64_t n) { const int64_t g = cdiv64(n, 4096); return g > 1024 ? 1024 : (g < 1 ? 1 : g); }
+__global__ void __launch_bounds__(256) sumsq_f32_kernel(const float* __restrict__ x, double* __restrict__ partial, int64_t n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += (double)x[i] * (double)x[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+extern "C" int neurst_sumsq_f32(const float* x, int64_t n, void* partial_f64, void* stream) {
+  NEURST_CHECK_ARG(x && partial_f64 && n > 0, "sumsq: bad args");
+  sumsq_f32_kernel<<<(int)neurst_sumsq_blocks(n), 256, 0, as_stream(stream)>>>(x, (double*)partial_f64, n);
+  NEURST_CHECK_LAUNCH("sumsq_f32");
+  return NEURST_OK;
+}
+
 extern "C" int neurst_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   NEURST_CHECK_ARG(n > 0, "cast: n <= 0");
   cast_f2b_kernel<<<grid_for(n, 256, 4), 256, 0, as_stream(stream)>>>(src, (bf16_t*)dst, n);

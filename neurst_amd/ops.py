@@ -504,6 +504,19 @@ def adam_step(p, g, m, v, shadow, lr_t, beta1, beta2, eps, grad_scale):
     _chk(_C.neurst_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()), 'adam_step')
 
 
+def axpy_f32(y, x, alpha):
+    """y += alpha * x (fp32, in place)."""
+    _chk(_C.neurst_axpy_f32(_p(y), _p(x), float(alpha), y.numel(), _s()), 'axpy_f32')
+
+
+def sumsq_f32(x):
+    """Sum of squares of an fp32 tensor: fp64 block partials on the device, summed on the host (one small read back)."""
+    nb = int(_C.neurst_sumsq_blocks(x.numel()))
+    part = torch.empty(nb, dtype=torch.float64, device=x.device)
+    _chk(_C.neurst_sumsq_f32(_p(x), x.numel(), _p(part), _s()), 'sumsq_f32')
+    return float(part.cpu().numpy().sum())
+
+
 def cast_f32_to_bf16(src, dst):
     _chk(_C.neurst_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _s()), 'cast_f32_to_bf16')
 

@@ -375,12 +375,15 @@ class TransformerTPE(Seq2SeqModel):
         mode = os.environ.get('NEURST_OVERLAP_ADAM') or 'off'
         mode = {'0': 'off', '1': 'backward'}.get(mode, mode)
         overlap = mode in ('tail', 'backward') and (not self.frozen) and self.graph.side_streams and self.device.type == 'cuda'
+        if self.args.lambda_l2 or self.args.grad_clip_global_norm:
+            overlap = False           # the L2 penalty and the global-norm clip need the complete averaged gradient before Adam
         self.bucketer.apply_in_backward = mode == 'backward'
         if overlap:
             lr, self.bucketer.apply_fn = self.optimizer_update_fn(self.store, 1.0 / self.bucketer.world)
         try:
             out4 = self.forward_backward(batch)
             scale = average_gradients(self.bucketer)
+            scale = handle_gradients(self.args, self.store, scale)      # gradientTools.py:40-67, after the tower mean (TransformerTPE.py:167-168)
         finally:
             self.bucketer.apply_fn = None
         if overlap:

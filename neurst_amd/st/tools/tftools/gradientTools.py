@@ -8,6 +8,8 @@ rest of backward; the 1/world_size of the mean is folded into the Adam kernel.
 import torch
 import os
 
+import numpy as np
+
 import torch.distributed as dist
 
 _DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
@@ -205,9 +207,24 @@ def average_gradients(bucketer):
     return bucketer.finish()
 
 
-def handle_gradients(args):
-    """gradientTools.py:40-67: L2 / clipping are all 0.0 in both templates; anything else is refused
-    rather than silently ignored."""
-    for k in ('lambda_l2', 'grad_clip_value', 'grad_clip_norm', 'grad_clip_global_norm'):
-        if getattr(args, k):
-            raise NotImplementedError('{} > 0 is outside the hot path (both templates use 0.0)'.format(k))
+def handle_gradients(args, store=None, scale=1.0):
+    """gradientTools.py:40-67 on the averaged gradients (`scale` * the summed arena): L2 penalty on every variable without
+    'bias' in its name (:47-48), tf.clip_by_global_norm (:60-65).  grad_clip_value / grad_clip_norm only touch variables
+    with 'lstm' in their name (:51-56) - none of this model's - so they are accepted and change nothing.  Returns the
+    scale Adam has to apply (the clip factor rides on it).  Called without a store (graph construction): checks only."""
+    lam = float(args.lambda_l2 or 0.0)
+    clip = float(args.grad_clip_global_norm or 0.0)
+    if lam < 0 or clip < 0:
+        raise ValueError('lambda_l2 / grad_clip_global_norm must be >= 0')
+    if store is None or (lam == 0.0 and clip == 0.0):
+        return scale
+    from .... import ops
+    if lam > 0.0:
+        for p in store.vars.values():
+            if 'bias' not in p.name:
+                # scale * (g + (lam / scale) v) = scale * g + lam * v
+                ops.axpy_f32(store.grads[p.offset:p.offset + p.size], store.params[p.offset:p.offset + p.size], lam / scale)
+    if clip > 0.0:
+        norm = scale * float(np.sqrt(ops.sumsq_f32(store.grads)))      # one 8 KB read back: clipping needs the norm on the host
+        scale = scale * clip / max(norm, clip)
+    return scale

@@ -587,11 +587,28 @@ def beam_decode_rerank(model: 'OracleTPE', P, enc, len_enc, beam_size, length_pe
     return preds_sorted, s_sorted, preds_sorted[:, 0, :], len_decoded
 
 
-def train_step(model: OracleTPE, P, M, V, batch, global_step, warmup_steps, peak, decay_steps, specaug_params=None):
-    """One optimisation step: lr from the pre-increment global_step (run_lut.py:346),
+def handle_gradients(grads, P, lambda_l2=0.0, grad_clip_global_norm=0.0):
+    """st/tools/tftools/gradientTools.py:40-67 for this model's variables: g += lambda_l2 * v unless 'bias' is in the variable's
+    name (:47-48); the value / norm clips (:51-56) only apply to variables named *lstm* - there are none; then
+    tf.clip_by_global_norm (:60-65): every g * clip / max(global_norm, clip), global_norm = sqrt(sum of all squares)."""
+    out = {}
+    for k, g in grads.items():
+        out[k] = g + g.dtype.type(lambda_l2) * P[k] if (lambda_l2 > 0 and 'bias' not in k) else g
+    if grad_clip_global_norm > 0:
+        gn = np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in out.values()))
+        f = grad_clip_global_norm / max(gn, grad_clip_global_norm)
+        out = {k: g * g.dtype.type(f) for k, g in out.items()}
+    return out
+
+
+def train_step(model: OracleTPE, P, M, V, batch, global_step, warmup_steps, peak, decay_steps, specaug_params=None, lambda_l2=0.0,
+               grad_clip_global_norm=0.0):
+    """One optimisation step: lr from the pre-increment global_step (run_lut.py:346), handle_gradients (TransformerTPE.py:167-168),
     TF Adam with beta1=.9, beta2=.98, eps=1e-9 hard-coded (lstmModel.py:526-530)."""
     model.step = global_step
     out = model.loss_and_grads(P, batch, specaug_params)
+    if lambda_l2 or grad_clip_global_norm:
+        out['grads'] = handle_gradients(out['grads'], P, lambda_l2, grad_clip_global_norm)
     lr = ops.warmup_exponential_decay(global_step, warmup_steps, peak, 0.5, decay_steps)
     t = global_step + 1
     for k in P:

@@ -233,6 +233,36 @@ def test_train_steps_follow_oracle_adam_and_lr(bucket_mb, overlap, monkeypatch):
             assert np.abs(Pd[k] - P[k])[sel].max() < 2e-4 * max(np.abs(P[k]).max(), 1e-3), k
 
 
+def test_l2_penalty_and_global_norm_clip_follow_the_oracle():
+    """handle_gradients (gradientTools.py:40-67): L2 on non-bias variables, then tf.clip_by_global_norm - three train steps
+    against the oracle's restatement, with a clip small enough to bind."""
+    args = ge.tiny_args(compute_dtype='fp32')
+    args.lambda_l2, args.grad_clip_global_norm = 0.05, 0.25
+    args.grad_clip_value, args.grad_clip_norm = 3.0, 2.0        # only touch *lstm* variables: accepted, no effect
+    model = make_model(args, step=0)
+    P = {k: v.astype(np.float64) for k, v in perturb(model).items()}
+    M = {k: np.zeros_like(v) for k, v in P.items()}
+    V = {k: np.zeros_like(v) for k, v in P.items()}
+    cfg = ge.oracle_cfg_from_args(args).zero_dropout()
+    orc = OracleTPE(cfg, is_train=True, dropout=False)
+    batch = make_batch(B=2, Traw=24, V=11, L=5, U=3, Lb=4, bert_dim=16, dim_raw=4, seed=1)
+    ob = oracle_batch(batch)
+    out0 = orc.loss_and_grads(P, ob, None)
+    gn = np.sqrt(sum(float((g ** 2).sum()) for g in out0['grads'].values()))
+    assert gn > 2 * args.grad_clip_global_norm                   # the clip binds
+    for step in range(3):
+        loss = model.train_step(batch)[0]
+        out, lr = oracle_train_step(orc, P, M, V, ob, step, args.warmup_steps, args.peak, args.decay_steps, lambda_l2=0.05,
+                                    grad_clip_global_norm=0.25)
+        assert abs(loss - out['loss']) < 3e-5 * abs(out['loss']), (step, loss, out['loss'])
+    Pd, Md = model.store.export(), model.store.export(model.store.m)
+    for k in P:
+        assert np.abs(Md[k] - M[k]).max() < 2e-4 * max(np.abs(M[k]).max(), 1e-6), k      # first moments: the handled gradients themselves
+        sel = np.sqrt(V[k]) > 1e-5
+        if sel.any():
+            assert np.abs(Pd[k] - P[k])[sel].max() < 2e-4 * max(np.abs(P[k]).max(), 1e-3), k
+
+
 def test_train_and_infer_models_share_variables():
     args = ge.tiny_args(compute_dtype='fp32')
     train = make_model(args)

@@ -26,3 +26,17 @@ def test_timing_signal_first_rows():
     s = ops.timing_signal(3, 6)
     assert np.allclose(s[0], [0, 0, 0, 1, 1, 1])
     assert np.isclose(s[1, 0], np.sin(1.0)) and np.isclose(s[1, 2], np.sin(1e-4), rtol=1e-5)
+
+
+def test_handle_gradients_known_answer():
+    """gradientTools.py:40-67 by hand: L2 skips names containing 'bias'; clip_by_global_norm scales by clip / max(norm, clip)."""
+    import numpy as np
+    from oracle.model import handle_gradients
+    g = {'a/kernel': np.array([3.0, 0.0]), 'a/bias': np.array([4.0])}
+    P = {'a/kernel': np.array([10.0, -10.0]), 'a/bias': np.array([100.0])}
+    out = handle_gradients(g, P, lambda_l2=0.1)
+    assert np.allclose(out['a/kernel'], [4.0, -1.0]) and np.allclose(out['a/bias'], [4.0])
+    out = handle_gradients(g, P, grad_clip_global_norm=2.5)            # norm 5 -> factor 0.5
+    assert np.allclose(out['a/kernel'], [1.5, 0.0]) and np.allclose(out['a/bias'], [2.0])
+    out = handle_gradients(g, P, grad_clip_global_norm=50.0)           # norm below the clip: unchanged
+    assert np.allclose(out['a/kernel'], [3.0, 0.0])
