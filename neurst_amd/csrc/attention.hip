@@ -180,6 +180,8 @@ struct AttnArgs {
   uint32_t* keep_bits;
   int nw;                // words per bitmap row
   int keep_bits_ready;   // forward: keep_bits already holds the decisions (neurst_mha_keep_bits): load them instead of hashing
+  int delta_local;       // backward, one launch for dQ and dK / dV: the dK / dV workgroups compute delta themselves
+  int nq_blocks, nk_tiles;   // that launch: its first nq_blocks blocks are dQ workgroups; key tiles per (batch, head)
 };
 
 // XCD-aware block placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order, so the tiles that share one
@@ -377,13 +379,11 @@ __global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : FWD_WPE)) mha_fwd
 // ================================================================== backward: delta + dQ
 // lane l works for query (l & 15): S^T = K.Q^T, dP^T = V.dO^T, dQ^T = K^T.dS^T; also writes delta = rowsum(dO * O)
 template <typename T, int DH, bool FULL>
-__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DQ_WPE)) mha_bwd_dq_kernel(AttnArgs a) {
+__device__ __forceinline__ void mha_bwd_dq_body(const AttnArgs& a, const BlockId bid, char* smem) {
   constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);             // [64][LDK]
   T* Vs = Ks + 64 * LDK;                          // [64][LDK]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
-  const BlockId bid = remap_block();
   const int64_t b = bid.z, h = bid.y, q0 = bid.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
@@ -479,20 +479,23 @@ __global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DQ_WPE)) mha_bwd_
     for (int dt = 0; dt < DH / 16; ++dt) store4<T>(dqrow, dt * 16 + g4, dh, dqacc[dt] * a.qscale, a.dq_vec);
   }
 }
+template <typename T, int DH, bool FULL>
+__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DQ_WPE)) mha_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  mha_bwd_dq_body<T, DH, FULL>(a, remap_block(), smem);
+}
 
 // ================================================================== backward: dK, dV
 // workgroup = 64 keys (16 per wave); lane l works for key (l & 15): S = Q.K^T, dP = dO.V^T, dV^T = dO^T.P, dK^T = Q^T.dS
 template <typename T, int DH, bool FULL>
-__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DKV_WPE)) mha_bwd_dkv_kernel(AttnArgs a) {
+__device__ __forceinline__ void mha_bwd_dkv_body(const AttnArgs& a, const BlockId bid, char* smem) {
   constexpr int KS = Mma<T>::KS, LDK = DH + ACfg<T>::PAD;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Qs = reinterpret_cast<T*>(smem);                 // [64][LDK]
   T* dOs = Qs + 64 * LDK;                             // [64][LDK]
   float* lse_s = reinterpret_cast<float*>(dOs + 64 * LDK);  // [64]
   float* del_s = lse_s + 64;                          // [64]
   uint32_t* mask_s = reinterpret_cast<uint32_t*>(del_s + 64);   // [2][64]: the two bitmap words of this 64-key tile for each of the 64 staged queries
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = (lane >> 4) * 4;
-  const BlockId bid = remap_block();
   const int64_t b = bid.z, h = bid.y, kv0 = bid.x * 64;
   const int dh = a.dh;
   const T* qg = reinterpret_cast<const T*>(a.q) + b * a.bsq + h * dh;
@@ -521,8 +524,26 @@ __global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DKV_WPE)) mha_bwd
   const bool stored = a.thr != 0;       // dropout: the words come from the bitmap, or are drawn again here when there is none
   auto load_stats = [&](int64_t q0n) {
     const int64_t qi = q0n + tid;
-    if (tid < 64 && qi < a.Tq) { lse_reg = a.lse_in[bh * a.Tq + qi] * unit; del_reg = a.delta[bh * a.Tq + qi]; }
-    else { lse_reg = 0.f; del_reg = 0.f; }
+    if (tid < 64 && qi < a.Tq) {
+      lse_reg = a.lse_in[bh * a.Tq + qi] * unit;
+      if (a.delta_local) {      // fused launch: the dQ blocks that write delta run beside this one - rowsum(dO * O) again here
+        const T* orow = reinterpret_cast<const T*>(a.o) + b * a.bso + h * dh + qi * a.ldo;
+        const T* drow = dog + qi * a.ldo;
+        float d = 0.f;
+        if (sizeof(T) == 2 && a.o_aligned) {
+          for (int e = 0; e < dh; e += 8) {
+            const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(orow + e), d8 = *reinterpret_cast<const bf16x8*>(drow + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += (float)o8[j] * (float)d8[j];
+          }
+        } else {
+          for (int e = 0; e < dh; ++e) d += to_f32<T>(orow[e]) * to_f32<T>(drow[e]);
+        }
+        del_reg = d;
+      } else {
+        del_reg = a.delta[bh * a.Tq + qi];
+      }
+    } else { lse_reg = 0.f; del_reg = 0.f; }
     if (stored && tid >= 64 && tid < 192) {
       const int64_t qm = q0n + ((tid - 64) & 63), wi = (kv0 >> 5) + ((tid - 64) >> 6);
       if (qm < a.Tq && wi < a.nw)
@@ -632,8 +653,30 @@ __global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DKV_WPE)) mha_bwd
     }
   }
 }
+template <typename T, int DH, bool FULL>
+__global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DKV_WPE)) mha_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  mha_bwd_dkv_body<T, DH, FULL>(a, remap_block(), smem);
+}
+// Short-query shapes (Tq <= 64: decoder self / cross attention, KD attention): dQ and dK / dV in ONE launch.  Both are chains of
+// dependent tiles on a few hundred workgroups that leave the chip mostly idle; side by side they cost the longer of the two
+// instead of the sum.  Blocks 0 .. nq_blocks - 1 are the dQ workgroups (one per (head, batch)), the rest the dK / dV workgroups
+// (64 keys each), which compute delta = rowsum(dO * O) of their staged queries themselves (a.delta_local).
+template <typename T, int DH, bool FULL>
+__global__ void __launch_bounds__(256) ATT_OCC(2) mha_bwd_small_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lin = blockIdx.x;
+  if (lin < a.nq_blocks) {
+    mha_bwd_dq_body<T, DH, FULL>(a, BlockId{0, lin % (int)a.H, lin / (int)a.H}, smem);
+  } else {
+    const int id = lin - a.nq_blocks, nx = a.nk_tiles;
+    mha_bwd_dkv_body<T, DH, FULL>(a, BlockId{id % nx, (id / nx) % (int)a.H, id / (nx * (int)a.H)}, smem);
+  }
+}
 
 // ================================================================== host side
+// neurst_set_option("mha_small_fused", 0) / NEURST_MHA_SMALL_FUSED=0: dQ and dK / dV of short-query shapes as two launches
+int g_opt_mha_small_fused = [] { const char* e = getenv("NEURST_MHA_SMALL_FUSED"); return e ? atoi(e) : 1; }();
 template <typename T, int DH> static size_t fwd_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
 template <typename T, int DH> static size_t dq_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD); }
 template <typename T, int DH> static size_t dkv_smem() { return sizeof(T) * 2 * 64 * (DH + ACfg<T>::PAD) + 128 * sizeof(float) + 128 * sizeof(uint32_t); }
@@ -825,6 +868,16 @@ extern "C" int neurst_mha_bwd_train_ws(const void* q, const void* k, const void*
   }
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)H, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)H, (unsigned)B);
+  // (two waves per SIMD: every instantiation spills less than its two stand-alone kernels do at three)
+  if (Tq <= 64 && g_opt_mha_small_fused && B * H * (1 + cdiv64(Tk, 64)) < (1ll << 30)) {
+    a.delta_local = 1;
+    a.nq_blocks = (int)(B * H);
+    a.nk_tiles = (int)cdiv64(Tk, 64);
+    dim3 gs((unsigned)(B * H * (1 + cdiv64(Tk, 64))));
+    if (dtype == NEURST_BF16) DISPATCH_DH(bf16_t, mha_bwd_small_kernel, dkv_smem, gs, "mha_bwd_small");
+    else DISPATCH_DH(float, mha_bwd_small_kernel, dkv_smem, gs, "mha_bwd_small");
+    return rc;
+  }
   if (dtype == NEURST_BF16) DISPATCH_DH(bf16_t, mha_bwd_dq_kernel, dq_smem, gq, "mha_bwd_dq");
   else DISPATCH_DH(float, mha_bwd_dq_kernel, dq_smem, gq, "mha_bwd_dq");
   if (rc) return rc;

@@ -727,9 +727,11 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int g_opt_fwd_ablate = 0;          // diagnostic: timing-only ablations of the wide forward (wrong results)
+extern int g_opt_mha_small_fused;         // attention.hip
 static int g_opt_mha_fused = 1;           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
 int neurst_attention2_set_option(const char* name, int value) {
   if (!strcmp(name, "mha_fused")) { g_opt_mha_fused = value; return 1; }
+  if (!strcmp(name, "mha_small_fused")) { g_opt_mha_small_fused = value; return 1; }
   if (!strcmp(name, "mha_fwd_ablate")) { g_opt_fwd_ablate = value; return 1; }
   return 0;
 }

@@ -430,6 +430,36 @@ def test_attention_fwd_bwd(dtype, tol, B, H, Tq, Tk, dh, mode, rate, stored):
     assert relerr(host(dq), dq_r) < tol and relerr(host(dk), dk_r) < tol and relerr(host(dv), dv_r) < tol
 
 
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('B,H,Tq,Tk,dh,mode,rate', [(3, 2, 40, 500, 96, 'keypad', 0.1), (2, 4, 40, 40, 96, 'causal', 0.1), (2, 1, 40, 300, 192, 'none', 0.0),
+                                                   (2, 2, 64, 130, 64, 'keypad', 0.0), (1, 2, 7, 70, 32, 'keypad', 0.2)])
+def test_attention_short_query_backward_in_one_launch(dtype, tol, B, H, Tq, Tk, dh, mode, rate):
+    """Tq <= 64 (decoder self / cross attention, KD attention): dQ and dK / dV in one launch, the dK / dV workgroups computing
+    delta themselves, against the two-launch path on the same inputs (delta summed in another order: not bit-identical)."""
+    rng = np.random.default_rng(Tk + dh)
+    td = torch.float32 if dtype == 'f32' else torch.bfloat16
+    d = H * dh
+    mk = lambda *s: dev(bf16_round(rng.standard_normal(s)), td)
+    q, k, v, do = mk(B, Tq, d), mk(B, Tk, d), mk(B, Tk, d), mk(B, Tq, d)
+    lens = np.array([Tk, max(Tk // 3, 1), 0][:B], np.int32)
+    mm = {'none': O.MASK_NONE, 'keypad': O.MASK_KEYPAD, 'causal': O.MASK_CAUSAL}[mode]
+    ld = dev(lens) if mode == 'keypad' else None
+    key = O.site_key(5, 77, 2)
+    o, lse, kb = ops.mha_fwd(q, k, v, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=True)
+    res = []
+    for fused in (1, 0):
+        ops.set_option('mha_small_fused', fused)
+        try:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ops.mha_bwd(q, k, v, o, do, lse, dq, dk, dv, d, d, d, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=kb if rate else None)
+            res.append([host(t.float()) for t in (dq, dk, dv)])
+        finally:
+            ops.set_option('mha_small_fused', 1)
+    for a_, b_ in zip(*res):
+        assert relerr(a_, b_) < tol
+    assert np.array_equal(res[0][0], res[1][0])          # dQ does not depend on who computes delta for dK / dV
+
+
 FUSED_BWD_CASES = [
     # B, H, Tq, Tk, mode, rate      (dh = 96, bf16: the shapes the fused backward kernel takes)
     (2, 2, 130, 130, 'keypad', 0.1),      # one key block, ragged query slices
