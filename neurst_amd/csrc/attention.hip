@@ -181,7 +181,7 @@ struct AttnArgs {
   int nw;                // words per bitmap row
   int keep_bits_ready;   // forward: keep_bits already holds the decisions (neurst_mha_keep_bits): load them instead of hashing
   int delta_local;       // backward, one launch for dQ and dK / dV: the dK / dV workgroups compute delta themselves
-  int nq_blocks, nk_tiles;   // that launch: its first nq_blocks blocks are dQ workgroups; key tiles per (batch, head)
+  int nq_blocks, nq_tiles, nk_tiles;   // that launch: its first nq_blocks blocks are dQ workgroups; query / key tiles per (batch, head)
 };
 
 // XCD-aware block placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order, so the tiles that share one
@@ -658,16 +658,17 @@ __global__ void __launch_bounds__(256) ATT_OCC((DH > 128 ? 2 : DKV_WPE)) mha_bwd
   extern __shared__ __attribute__((aligned(16))) char smem[];
   mha_bwd_dkv_body<T, DH, FULL>(a, remap_block(), smem);
 }
-// Short-query shapes (Tq <= 64: decoder self / cross attention, KD attention): dQ and dK / dV in ONE launch.  Both are chains of
+// Short-query shapes (Tq <= 256: decoder self / cross attention, KD attention): dQ and dK / dV in ONE launch.  Both are chains of
 // dependent tiles on a few hundred workgroups that leave the chip mostly idle; side by side they cost the longer of the two
-// instead of the sum.  Blocks 0 .. nq_blocks - 1 are the dQ workgroups (one per (head, batch)), the rest the dK / dV workgroups
-// (64 keys each), which compute delta = rowsum(dO * O) of their staged queries themselves (a.delta_local).
+// instead of the sum.  Blocks 0 .. nq_blocks - 1 are the dQ workgroups (64 queries of one (head, batch) each), the rest the dK / dV workgroups
+// (64 keys each), which compute delta = rowsum(dO * O) of every query tile they stage themselves (a.delta_local).
 template <typename T, int DH, bool FULL>
 __global__ void __launch_bounds__(256) ATT_OCC(2) mha_bwd_small_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lin = blockIdx.x;
   if (lin < a.nq_blocks) {
-    mha_bwd_dq_body<T, DH, FULL>(a, BlockId{0, lin % (int)a.H, lin / (int)a.H}, smem);
+    const int nqt = a.nq_tiles;
+    mha_bwd_dq_body<T, DH, FULL>(a, BlockId{lin % nqt, (lin / nqt) % (int)a.H, lin / (nqt * (int)a.H)}, smem);
   } else {
     const int id = lin - a.nq_blocks, nx = a.nk_tiles;
     mha_bwd_dkv_body<T, DH, FULL>(a, BlockId{id % nx, (id / nx) % (int)a.H, id / (nx * (int)a.H)}, smem);
@@ -869,11 +870,12 @@ extern "C" int neurst_mha_bwd_train_ws(const void* q, const void* k, const void*
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)H, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)H, (unsigned)B);
   // (two waves per SIMD: every instantiation spills less than its two stand-alone kernels do at three)
-  if (Tq <= 64 && g_opt_mha_small_fused && B * H * (1 + cdiv64(Tk, 64)) < (1ll << 30)) {
+  if (Tq <= 256 && g_opt_mha_small_fused && B * H * (cdiv64(Tq, 64) + cdiv64(Tk, 64)) < (1ll << 30)) {
     a.delta_local = 1;
-    a.nq_blocks = (int)(B * H);
+    a.nq_tiles = (int)cdiv64(Tq, 64);
+    a.nq_blocks = (int)(B * H * a.nq_tiles);
     a.nk_tiles = (int)cdiv64(Tk, 64);
-    dim3 gs((unsigned)(B * H * (1 + cdiv64(Tk, 64))));
+    dim3 gs((unsigned)(B * H * (a.nq_tiles + a.nk_tiles)));
     if (dtype == NEURST_BF16) DISPATCH_DH(bf16_t, mha_bwd_small_kernel, dkv_smem, gs, "mha_bwd_small");
     else DISPATCH_DH(float, mha_bwd_small_kernel, dkv_smem, gs, "mha_bwd_small");
     return rc;

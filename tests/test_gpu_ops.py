@@ -432,9 +432,10 @@ def test_attention_fwd_bwd(dtype, tol, B, H, Tq, Tk, dh, mode, rate, stored):
 
 @pytest.mark.parametrize('dtype,tol', [('f32', 1e-5), ('bf16', 2e-2)])
 @pytest.mark.parametrize('B,H,Tq,Tk,dh,mode,rate', [(3, 2, 40, 500, 96, 'keypad', 0.1), (2, 4, 40, 40, 96, 'causal', 0.1), (2, 1, 40, 300, 192, 'none', 0.0),
-                                                   (2, 2, 64, 130, 64, 'keypad', 0.0), (1, 2, 7, 70, 32, 'keypad', 0.2)])
+                                                   (2, 2, 64, 130, 64, 'keypad', 0.0), (1, 2, 7, 70, 32, 'keypad', 0.2),
+                                                   (2, 2, 80, 80, 64, 'causal', 0.1), (2, 2, 200, 330, 64, 'keypad', 0.1)])
 def test_attention_short_query_backward_in_one_launch(dtype, tol, B, H, Tq, Tk, dh, mode, rate):
-    """Tq <= 64 (decoder self / cross attention, KD attention): dQ and dK / dV in one launch, the dK / dV workgroups computing
+    """Tq <= 256 (decoder self / cross attention, KD attention): dQ and dK / dV in one launch, the dK / dV workgroups computing
     delta themselves, against the two-launch path on the same inputs (delta summed in another order: not bit-identical)."""
     rng = np.random.default_rng(Tk + dh)
     td = torch.float32 if dtype == 'f32' else torch.bfloat16
