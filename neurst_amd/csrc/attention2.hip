@@ -59,7 +59,8 @@ __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, int voff) {
 // [rows][192 B] image (Q / dO slice, K block): 16-byte chunk ch of a row sits at chunk ch ^ ((row >> 2) & 3) - conflict-free
 // for the b128 row reads of the 32x32x16 A operand and for the transposed reads of both MFMA shapes (tools/exp/lds_banks.py)
 constexpr int ROWB = 192;
-__device__ __forceinline__ int img_off(int row, int ch) { return row * ROWB + 16 * (ch ^ ((row >> 2) & 3)); }
+template <int RB = ROWB>
+__device__ __forceinline__ int img_off(int row, int ch) { return row * RB + 16 * (ch ^ ((row >> 2) & 3)); }
 // dS^T image [256 keys][32 queries] bf16, 64-byte rows, 8-byte slot s at slot s ^ ((row >> 1) & 7)
 __device__ __forceinline__ int dst_off(int row, int slot) { return row * 64 + 8 * (slot ^ ((row >> 1) & 7)); }
 
@@ -79,6 +80,7 @@ constexpr int MAX_TQ = 2048;   // statistics of every query stay in LDS
 
 template <int DH> struct Lds {
   static constexpr int CH = DH / 8;                       // 16-byte chunks per row
+  static constexpr int ROWB = DH * 2;                     // row pitch of the images = the row itself (192 B at dh = 96, 128 B at 64)
   static constexpr int KIMG = 0, KIMG_B = KB * ROWB;
   static constexpr int QS0 = KIMG + KIMG_B, SLICE_B = QS * ROWB;
   static constexpr int DO0 = QS0 + 2 * SLICE_B;
@@ -91,6 +93,7 @@ template <int DH> struct Lds {
 template <int DH, bool DROP, bool STAMPS>
 __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   typedef Lds<DH> L;
+  constexpr int ROWB = DH * 2;      // row pitch of the LDS images (the LDS-DMA writes rows back to back)
   constexpr int KS = DH / 16;       // k-steps of a product over d (32x32x16)
   constexpr int DB = DH / 32;       // 32-wide d blocks of dK^T / dV^T
   constexpr int NT = DH / 32;       // 16-wide d blocks of dQ per wave (DH/16 blocks over the two wave pairs)
@@ -201,8 +204,8 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   int trk_lo[NT], trk_hi[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    trk_lo[n] = img_off(8 * G + qq, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
-    trk_hi[n] = img_off(8 * G + qq + 4, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
+    trk_lo[n] = img_off<ROWB>(8 * G + qq, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
+    trk_hi[n] = img_off<ROWB>(8 * G + qq + 4, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
   }
   // dS^T stores: key row 64 w + 32 blk + c, slot 2 j + g
   const int krow = 64 * w + c;
@@ -497,6 +500,7 @@ __device__ __forceinline__ void halves(float x, float& lo, float& hi) {
 constexpr int KBF = 128;       // keys per block
 constexpr int FW = 8;          // waves
 template <int DH> struct LdsF {
+  static constexpr int ROWB = DH * 2;
   static constexpr int IMG_B = KBF * ROWB;
   static constexpr int K0 = 0, V0 = 2 * IMG_B;              // [2 buffers] each
   static constexpr int OST0 = 4 * IMG_B, OST_B = QS * ROWB;  // per-wave output staging tile
@@ -518,6 +522,7 @@ struct FwdArgs {
 template <int DH, bool DROP, int ABL = 0>
 __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
   typedef LdsF<DH> L;
+  constexpr int ROWB = DH * 2;
   constexpr int KS = DH / 16, DB = DH / 32, CH = DH / 8;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, g = lane >> 5;
@@ -728,7 +733,7 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int g_opt_fwd_ablate = 0;          // diagnostic: timing-only ablations of the wide forward (wrong results)
 extern int g_opt_mha_small_fused;         // attention.hip
-static int g_opt_mha_fused = 1;           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
+static int g_opt_mha_fused = [] { const char* e = getenv("NEURST_MHA_FUSED"); return e ? atoi(e) : 1; }();           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
 int neurst_attention2_set_option(const char* name, int value) {
   if (!strcmp(name, "mha_fused")) { g_opt_mha_fused = value; return 1; }
   if (!strcmp(name, "mha_small_fused")) { g_opt_mha_small_fused = value; return 1; }
@@ -743,7 +748,7 @@ extern "C" int64_t neurst_mha_bwd_workspace_bytes(int64_t B, int64_t H, int64_t 
 
 bool neurst_mha2_bwd_eligible(const Mha2Problem& p, int64_t ws_bytes) {
   if (!g_opt_mha_fused || p.dtype != NEURST_BF16) return false;
-  if (p.dh != 96) return false;
+  if (p.dh != 96 && p.dh != 64) return false;
   if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
   if (p.Tq > a2::MAX_TQ || p.B * p.H > 65535 * 16) return false;
   if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128)) return false;
@@ -774,9 +779,10 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
   a.qscale = 1.0f / sqrtf((float)p.dh);
   a.keep_scale = keep_scale(p.rate);
   const int tqp = (int)cdiv64(p.Tq, a2::QS) * a2::QS;
-  const size_t smem = a2::Lds<96>::bytes(tqp);
+  const size_t smem = p.dh == 96 ? a2::Lds<96>::bytes(tqp) : a2::Lds<64>::bytes(tqp);
   auto kern = a.stamps ? a2::mha2_bwd_kernel<96, true, true>
                        : (p.rate > 0.f ? a2::mha2_bwd_kernel<96, true, false> : a2::mha2_bwd_kernel<96, false, false>);
+  if (p.dh == 64) kern = p.rate > 0.f ? a2::mha2_bwd_kernel<64, true, false> : a2::mha2_bwd_kernel<64, false, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) { neurst_set_error("mha2_bwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
   kern<<<dim3((unsigned)(p.B * p.H)), 256, smem, s>>>(a);
@@ -786,7 +792,7 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
 
 // ---- forward -------------------------------------------------------------------------------------------------------
 bool neurst_mha2_fwd_eligible(const Mha2FwdProblem& p) {
-  if (!g_opt_mha_fused || p.dtype != NEURST_BF16 || p.dh != 96) return false;
+  if (!g_opt_mha_fused || p.dtype != NEURST_BF16 || (p.dh != 96 && p.dh != 64)) return false;
   if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
   if (p.B * p.H > 65535 * 16) return false;
   if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128)) return false;
@@ -808,9 +814,10 @@ int neurst_mha2_fwd_launch(const Mha2FwdProblem& p, hipStream_t s) {
   a.idx32 = (double)p.B * (double)p.H * (double)p.Tq * (double)a.nw * 4.0 < 4294967296.0;
   a.qscale = 1.0f / sqrtf((float)p.dh);
   a.keep_scale = keep_scale(p.rate);
-  const size_t smem = a2::LdsF<96>::BYTES;
+  const size_t smem = p.dh == 96 ? a2::LdsF<96>::BYTES : a2::LdsF<64>::BYTES;
   auto kern = p.rate > 0.f ? a2::mha2_fwd_kernel<96, true> : a2::mha2_fwd_kernel<96, false>;
-  switch (g_opt_fwd_ablate) {
+  if (p.dh == 64) kern = p.rate > 0.f ? a2::mha2_fwd_kernel<64, true> : a2::mha2_fwd_kernel<64, false>;
+  else switch (g_opt_fwd_ablate) {
     case 1: kern = a2::mha2_fwd_kernel<96, false, 1>; break;
     case 2: kern = a2::mha2_fwd_kernel<96, false, 2>; break;
     case 4: kern = a2::mha2_fwd_kernel<96, false, 4>; break;

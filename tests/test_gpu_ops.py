@@ -471,12 +471,13 @@ FUSED_BWD_CASES = [
 ]
 
 
+@pytest.mark.parametrize('dh', [96, 64])
 @pytest.mark.parametrize('B,H,Tq,Tk,mode,rate', FUSED_BWD_CASES)
-def test_attention_fused_backward(B, H, Tq, Tk, mode, rate):
+def test_attention_fused_backward(B, H, Tq, Tk, mode, rate, dh):
     """the one-kernel backward (attention2.hip) against the oracle and against the dq + dkv kernel pair on the same inputs"""
     from neurst_amd import lib
     Clib = lib.load()
-    dh, td, tol = 96, torch.bfloat16, 3e-2
+    td, tol = torch.bfloat16, 3e-2
     rng = np.random.default_rng(Tq * 3 + Tk)
     d = H * dh
     q, k, v, do = (bf16_round(rng.standard_normal((B, T_, d)).astype(np.float32) * 0.7) for T_ in (Tq, Tk, Tk, Tq))
@@ -488,6 +489,8 @@ def test_attention_fused_backward(B, H, Tq, Tk, mode, rate):
     qd, kd, vd = dev(q, td), dev(k, td), dev(v, td)
     ld = dev(lens) if mode == 'keypad' else None
     o, lse, kb = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=True)
+    live_f = slice(0, 2) if B == 3 else slice(None)
+    assert relerr(host(o)[live_f], ref[live_f]) < tol          # the wide forward (attention2.hip) takes these shapes too
     outs = {}
     try:
         for fused in (2, 0):
