@@ -109,6 +109,39 @@ def test_fp32_cnn_frontend_matches_oracle():
     compare_grads(model, ref, 1e-4)
 
 
+def test_bf16_cnn_frontend_fast_paths_within_tolerance():
+    """use_cnn_resample in bf16 with 32 filters: the first layer takes the one-K-step MFMA kernel (kh kw Cin = 9), the second the
+    3x3 implicit-GEMM kernels (forward, data gradient, im2col weight gradient), the max pool its vector path.  The step runs
+    once with the fast paths and once with the general kernels (neurst_set_option conv_fast 0): loss against the fp64 oracle
+    at 2e-2, every gradient at 0.3 of its largest element (d_model 16 in bf16: the general kernels sit at 0.27 on the decoder's
+    query bias), and the two kernel sets within 0.03 of each other, which is what pins the fast paths inside the model."""
+    from neurst_amd import ops
+    args = ge.tiny_args(compute_dtype='bf16', loss_type='ce_ctc', use_cnn_resample=True, cnn={'layers': 2, 'kernel': '3,3', 'stride': '2,2'},
+                        num_filters=32)
+    batch = make_batch(B=2, Traw=37, V=11, L=5, U=3, raw=False, dim_input=24, ragged=True, seed=5)
+    got = {}
+    try:
+        for fast in (1, 0):
+            ops.set_option('conv_fast', fast)
+            model = make_model(args)
+            if fast:
+                P = perturb(model)
+                P = {k: (torch.from_numpy(v).bfloat16().float().numpy() if v.ndim > 1 and 'embedding' not in k else v) for k, v in P.items()}
+                cfg = ge.oracle_cfg_from_args(args).zero_dropout()
+                ref = OracleTPE(cfg, is_train=True, dropout=False).loss_and_grads({k: v.astype(np.float64) for k, v in P.items()}, batch)
+            model.store.load_params(P)
+            out4 = model.forward_backward(batch).cpu().numpy()
+            assert abs(out4[0] - ref['loss']) < 2e-2 * abs(ref['loss'])
+            compare_grads(model, ref, 0.3)
+            got[fast] = (out4, model.store.export_grads())
+    finally:
+        ops.set_option('conv_fast', 1)
+    assert abs(got[1][0][0] - got[0][0][0]) < 2e-3 * abs(ref['loss'])
+    for k, v in got[0][1].items():
+        err = np.abs(got[1][1][k] - v).max() / max(np.abs(v).max(), 1e-7)
+        assert err < 0.03, (k, err)
+
+
 def test_fp32_dropout_and_specaug_parity_with_oracle_hash():
     over = dict(loss_type='ce_ctc', use_specAug=True)
     args = ge.tiny_args(compute_dtype='fp32', **over)
