@@ -294,25 +294,46 @@ extern "C" int neurst_embedding_bwd(const int32_t* ids, const void* dout, float*
 }
 
 // ---------------------------------------------------------------- a20 Adam (flat arena, 16 B per lane)
+// EPT 16-byte elements per thread (all loads issued before the first use); NT: streaming hints - every arena is touched once
+// per step and is larger than the Infinity Cache, so keeping its lines helps nobody
+template <int EPT, bool NTEMP>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             bf16_t* __restrict__ shadow, int64_t n, float lr_t, float b1, float b2, float eps, float gs) {
   const int64_t n4 = n >> 2;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+  auto ld = [](const float* q, int64_t i) __attribute__((always_inline)) {
+    const f32x4* a = reinterpret_cast<const f32x4*>(q) + i;
+    if constexpr (NTEMP) return __builtin_nontemporal_load(a);
+    else return *a;
+  };
+  auto st = [](float* q, int64_t i, f32x4 x) __attribute__((always_inline)) {
+    f32x4* a = reinterpret_cast<f32x4*>(q) + i;
+    if constexpr (NTEMP) __builtin_nontemporal_store(x, a);
+    else *a = x;
+  };
+  const int64_t i0 = (blockIdx.x * (int64_t)blockDim.x) * EPT + threadIdx.x;
+  f32x4 pp[EPT], gg[EPT], mm[EPT], vv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = i0 + (int64_t)e * blockDim.x;
+    if (i < n4) { pp[e] = ld(p, i); gg[e] = ld(g, i); mm[e] = ld(m, i); vv[e] = ld(v, i); }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int64_t i = i0 + (int64_t)e * blockDim.x;
+    if (i >= n4) break;
     bf16x4 sh;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float gj = gg[j] * gs;
-      mm[j] = b1 * mm[j] + (1.f - b1) * gj;
-      vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
-      pp[j] = pp[j] - lr_t * mm[j] / (sqrtf(vv[j]) + eps);
-      sh[j] = (bf16_t)pp[j];
+      float gj = gg[e][j] * gs;
+      mm[e][j] = b1 * mm[e][j] + (1.f - b1) * gj;
+      vv[e][j] = b2 * vv[e][j] + (1.f - b2) * gj * gj;
+      pp[e][j] = pp[e][j] - lr_t * mm[e][j] / (sqrtf(vv[e][j]) + eps);
+      sh[j] = (bf16_t)pp[e][j];
     }
-    reinterpret_cast<f32x4*>(p)[i] = pp;
-    reinterpret_cast<f32x4*>(m)[i] = mm;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
-    if (shadow) reinterpret_cast<bf16x4*>(shadow)[i] = sh;
+    st(p, i, pp[e]);
+    st(m, i, mm[e]);
+    st(v, i, vv[e]);
+    if (shadow) reinterpret_cast<bf16x4*>(shadow)[i] = sh;      // read again by the next step's first kernels: no hint
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -330,11 +351,18 @@ extern "C" int neurst_adam_step(float* p, const float* g, float* m, float* v, vo
   NEURST_CHECK_ARG(n > 0, "adam_step: n <= 0");
   NEURST_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: arenas must be 16-byte aligned");
   NEURST_CHECK_ARG(((uintptr_t)shadow_bf16 & 7) == 0, "adam_step: shadow must be 8-byte aligned");
-  // one 16-byte element per thread, no grid-stride loop: measured 5.1 vs 4.5 TB/s against an 8192-block persistent grid
-  int64_t ablocks = cdiv64(n >> 2, 256);
-  if (ablocks > (1 << 20)) ablocks = 1 << 20;
+  // Two 16-byte elements per thread with streaming hints, no grid-stride loop.  Measured on the LUT arenas (120.3 M
+  // parameters): 578 us = 6.2 TB/s; one element per thread 681 us with or without the hints, two without them 681, three
+  // or four with them 584; an 8192-block persistent grid 4.5 TB/s.  NEURST_ADAM_VARIANT=0: one element, no hints (A/B timing).
+  static const int variant = [] { const char* e = getenv("NEURST_ADAM_VARIANT"); return e ? atoi(e) : 2; }();
+  const int ept = variant == 0 ? 1 : 2;
+  int64_t ablocks = cdiv64(n >> 2, 256 * ept);
+  NEURST_CHECK_ARG(ablocks < (int64_t)1 << 31, "adam_step: n too large for one launch");
   if (ablocks < 1) ablocks = 1;
-  adam_kernel<<<(unsigned)ablocks, 256, 0, as_stream(stream)>>>(p, g, m, v, (bf16_t*)shadow_bf16, n, lr_t, beta1, beta2, eps, grad_scale);
+#define ADAM(EPT, NTEMP) adam_kernel<EPT, NTEMP><<<(unsigned)ablocks, 256, 0, as_stream(stream)>>>(p, g, m, v, (bf16_t*)shadow_bf16, n, lr_t, beta1, beta2, eps, grad_scale)
+  if (variant == 0) ADAM(1, false);
+  else ADAM(2, true);
+#undef ADAM
   NEURST_CHECK_LAUNCH("adam_step");
   return NEURST_OK;
 }

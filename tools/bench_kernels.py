@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel-level timing (HIP events, interleaved rounds in one process) of the GEMM / attention / LN shapes
-of the LUT step.  Usage: python tools/bench_kernels.py [gemm|attn|ln|conv|all]"""
+of the LUT step.  Usage: python tools/bench_kernels.py [gemm|attn|ln|conv|adam|all]"""
 import os
 import sys
 
@@ -122,6 +122,16 @@ def bench_ln():
         print('ln bwd rate=%.1f %7.1f us  %6.0f GB/s (%d*rows*C*2 B)' % (rate, m, (4 if rate else 3) * rows * C * 2 / m / 1e3, 4 if rate else 3))
 
 
+def bench_adam():
+    """the LUT model's arenas: 120.3 M fp32 parameters, 30 B per parameter and step (p, g, m, v in; p, m, v, bf16 copy out)"""
+    n = int(os.environ.get('ADAM_N', '120300000'))
+    p, g = torch.randn(n, device=DEV), torch.randn(n, device=DEV) * 1e-3
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sh = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    med, mn = timeit(lambda: ops.adam_step(p, g, m, v, sh, 1e-4, 0.9, 0.98, 1e-9, 1.0), reps=15)
+    print('adam n=%d  med %7.1f us  min %7.1f us  %6.0f GB/s (30 B per parameter)' % (n, med, mn, 30.0 * n / med / 1e3))
+
+
 def bench_conv():
     """a4: the two conv + LN + ReLU layers of a `use_cnn_resample` front end at BASELINE config 2's input (32 x 1500 x 80),
     3 x 3 kernels, stride 2, 64 filters (transformer_encoder.py:69-95), and the 3 x 3 max pool behind them.  Algorithmic
@@ -162,5 +172,7 @@ if __name__ == '__main__':
         bench_attn()
     if what in ('ln', 'all'):
         bench_ln()
+    if what in ('adam', 'all'):
+        bench_adam()
     if what in ('conv', 'all'):
         bench_conv()
