@@ -745,9 +745,11 @@ def test_conv_fast_paths_agree_with_the_general_kernels():
     assert (res[0][0] != res[1][0]).mean() < 1e-3            # conv_out: bit-equal but for rare rounding flips
 
 
-def test_adam_matches_tf_formula():
+@pytest.mark.parametrize('n', [1003, 7 * 2048 + 1025, 3])
+def test_adam_matches_tf_formula(n):
+    """n: a partial first workgroup, several workgroups of two 16-byte elements per thread with the second element of the
+    last one partly past the end, fewer than four parameters; the words behind the arenas stay untouched."""
     rng = np.random.default_rng(13)
-    n = 1003
     p, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
     m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
     pad = lambda a: dev(np.concatenate([a, np.zeros(21, np.float32)]))
@@ -761,6 +763,8 @@ def test_adam_matches_tf_formula():
         p, m, v = O.adam_step(p, 0.5 * g, m, v, lr, t)
     assert relerr(host(pd)[:n], p) < 1e-6 and relerr(host(vd)[:n], v) < 1e-6
     assert relerr(host(sh)[:n], p) < 1e-2
+    for t_ in (pd, md, vd, sh):
+        assert not host(t_.float())[n:].any()
 
 
 def _np_topk(x, k):
