@@ -191,6 +191,24 @@ def side_wgrad_rows_from_env():
     return (int(lo), int(hi)) if hi else (1, int(lo))
 
 
+class _Scope:
+    """`with g.variable_scope(name):` - a plain object instead of a generator-based context manager: a step opens ~400."""
+    __slots__ = ('g', 'name')
+
+    def __init__(self, g, name):
+        self.g, self.name = g, name
+
+    def __enter__(self):
+        g, name = self.g, self.name
+        g.scopes.append(name)
+        g.prefixes.append(g.prefixes[-1] + name + '/' if name else g.prefixes[-1])
+
+    def __exit__(self, *exc):
+        self.g.scopes.pop()
+        self.g.prefixes.pop()
+        return False
+
+
 class Graph:
     """One model's execution context (TF: default graph + variable scope + train/eval flag)."""
 
@@ -201,6 +219,7 @@ class Graph:
         self.step = 0
         self.tape = None
         self.scopes = []
+        self.prefixes = ['']        # per open scope: the joined names so far, '/'-terminated (hundreds of lookups per step)
         self.auto_site = 10_000
         self.name_counts = {}
         self.dropout_enabled = True
@@ -235,18 +254,13 @@ class Graph:
         self.pending_tiles = 0
         self.pending_reads = set()
 
-    @contextlib.contextmanager
     def variable_scope(self, name):
-        self.scopes.append(name)
-        try:
-            yield
-        finally:
-            self.scopes.pop()
+        return _Scope(self, name)
 
     def default_scope(self, default_name):
         """tf.variable_scope(None, default_name=...): first use keeps the name, later uses in the
         same enclosing scope get _1, _2, ... (reset by begin_forward)."""
-        k = (self.scope_name(), default_name)
+        k = (self.prefixes[-1], default_name)
         n = self.name_counts.get(k, 0)
         self.name_counts[k] = n + 1
         return self.variable_scope(default_name if n == 0 else '{}_{}'.format(default_name, n))
@@ -259,11 +273,10 @@ class Graph:
             self.step = step
 
     def scope_name(self):
-        return '/'.join(s for s in self.scopes if s)
+        return self.prefixes[-1][:-1]
 
     def get_variable(self, name, shape=None):
-        full = self.scope_name() + '/' + name if self.scopes else name
-        return self.store.get(full, shape)
+        return self.store.get(self.prefixes[-1] + name, shape)
 
     def key(self, site=None):
         if site is None:

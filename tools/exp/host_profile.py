@@ -42,4 +42,6 @@ for _ in range(steps):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(45)
+st.sort_stats('tottime').print_stats(int(os.environ.get('TOP', '45')))
+if os.environ.get('CUM'):
+    st.sort_stats('cumtime').print_stats(int(os.environ.get('TOP', '45')))
