@@ -387,8 +387,9 @@ class Graph:
     def defer_wgrad(self, dy2, x2, w, layout, bias):
         """Take the weight (+ bias) gradient of one dense layer into the pending group; False = not a case for the grouped
         kernel (the caller launches it the usual way).  param_grad_done is reported when the group is launched."""
-        M = x2.shape[0]
-        if (not self.group_wgrads or dy2.device.type != 'cuda' or dy2.dtype != torch.bfloat16 or M < self.group_min_rows
+        if x2.shape[0] < self.group_min_rows:       # first: the answer for every decoder-size layer (most calls)
+            return False
+        if (not self.group_wgrads or dy2.device.type != 'cuda' or dy2.dtype != torch.bfloat16
                 or not dy2.is_contiguous() or not x2.is_contiguous()):
             return False
         if layout == 'out_in':
