@@ -99,6 +99,21 @@ def main(tag):
                    'formula': 'MfmaUtil = 100 * sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM): share of the cycles a kernel was on the GPU in '
                               'which a SIMD had its matrix pipe busy, at the clock the chip held during that kernel',
                    'kernels': kernels}, open(os.path.join(dst, tag + '_mfma_util.json'), 'w'), indent=1)
+    lf = os.path.join(src, 'lds', 'l_counter_collection.csv')
+    if os.path.exists(lf):            # a fifth pass: --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = collections.defaultdict(int)
+        for r in csv.DictReader(open(lf)):
+            k = gemm_label(r['Kernel_Name']) or r['Kernel_Name'].split('(')[0]
+            acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+            n[k] += r['Counter_Name'] == 'SQ_LDS_IDX_ACTIVE'
+        kernels = {k: {'launches': n[k], 'lds_bank_conflict_cycles': round(v.get('SQ_LDS_BANK_CONFLICT', 0.0)),
+                       'lds_active_cycles': round(v.get('SQ_LDS_IDX_ACTIVE', 0.0)),
+                       'conflict_share_percent': round(100.0 * v.get('SQ_LDS_BANK_CONFLICT', 0.0) / v['SQ_LDS_IDX_ACTIVE'], 1)}
+                   for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get('SQ_LDS_IDX_ACTIVE', 0.0)) if v.get('SQ_LDS_IDX_ACTIVE', 0.0) > 0}
+        json.dump({'source': 'rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams',
+                   'formula': 'conflict_share = cycles the LDS spent on bank conflicts / cycles it was active, both summed over a kernel\'s launches',
+                   'kernels': kernels}, open(os.path.join(dst, tag + '_lds_conflicts.json'), 'w'), indent=1)
     print('wrote', os.listdir(dst))
 
 
