@@ -29,6 +29,13 @@ enum { NEURST_F32 = 0, NEURST_BF16 = 1 };
 enum { NEURST_OK = 0, NEURST_E_INVALID = -1, NEURST_E_LAUNCH = -2, NEURST_E_UNSUPPORTED = -3 };
 enum { NEURST_MASK_NONE = 0, NEURST_MASK_KEYPAD = 1, NEURST_MASK_CAUSAL = 2 };
 
+/* Version of this interface.  It changes whenever an existing entry point changes its argument list or the layout of a
+ * buffer it reads or writes (version 2: neurst_conv2d_ln_relu_bwd gained col_ws / col_ws_bytes and attention's keep_bits
+ * became a u32 row bitmap; version 3: the neurst_comm_* entry points and the bf16 / deferred-scale arguments of this round).
+ * neurst_abi_version() returns the value the library was built with: a host checks it against the header it compiled with
+ * (neurst_amd/lib.py does at load time and refuses a mismatch). */
+#define NEURST_ABI_VERSION 3
+
 const char* neurst_last_error(void);
 int neurst_abi_version(void);
 
@@ -93,8 +100,11 @@ int neurst_gemm_wgrad_bias_grouped(int n, const void* const* A, const void* cons
  * `dense`, st/models/tools/utils.py:367-398): only tiles tile_begin[i] .. tile_end[i] - 1 of problem i are computed (a
  * problem has neurst_gemm_wgrad_group_tiles(M_i, N_i) tiles of 256 x 192, independent of each other), so a caller can cut
  * the tiles of many layers into launches of exactly 256 - one workgroup per CU - with a layer straddling two launches
- * (st/models/graph.py).  Up to neurst_gemm_wgrad_group_max() problems.  When the tile kernel cannot take the operands
- * (fp32 operands, alignment) a problem is computed whole by the call whose range starts at tile 0. */
+ * (st/models/graph.py).  Up to neurst_gemm_wgrad_group_max() problems.  Whether the tile kernel takes a problem is decided
+ * PER PROBLEM from its own operands (bf16, 16-byte aligned rows, M % 8 == N % 8 == 0, 32-bit window), never from what
+ * else is queued in the call: eligible problems share one grouped launch, and a problem the tile kernel cannot take is
+ * computed whole by the call whose range starts at tile 0 - so the calls that hold the parts of a straddling problem agree
+ * as long as the `gemm256` option is not changed between them. */
 int neurst_gemm_wgrad_bias_grouped_tiles(int n, const void* const* A, const void* const* B, float* const* C,
                                          float* const* opsum, const int64_t* M, const int64_t* N, const int64_t* K,
                                          const int64_t* lda, const int64_t* ldb, const int64_t* ldc, const int* tile_begin,

@@ -751,11 +751,13 @@ bool neurst_mha2_bwd_eligible(const Mha2Problem& p, int64_t ws_bytes) {
   if (p.dh != 96 && p.dh != 64) return false;
   if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
   if (p.Tq > a2::MAX_TQ || p.B * p.H > 65535 * 16) return false;
-  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128)) return false;
+  // one workgroup per (batch, head): below ~half a chip of them (single-utterance inference) the tiled kernels of
+  // attention.hip, ceil(T / 64) workgroups per (batch, head), fill the CUs better
+  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128 || p.B * p.H < 128)) return false;
   if (ws_bytes < neurst_mha_bwd_workspace_bytes(p.B, p.H, p.Tq, p.Tk, p.dh)) return false;
   auto al16 = [](const void* x, int64_t ld) { return ((uintptr_t)x & 15) == 0 && (ld * 2) % 16 == 0; };
   if (!al16(p.q, p.ldq) || !al16(p.k, p.ldk) || !al16(p.v, p.ldv) || !al16(p.o, p.ldo) || !al16(p.d_o, p.ldo)) return false;
-  if (!al16(p.dk, p.lddk) || !al16(p.dv, p.lddv)) return false;
+  if (!al16(p.dk, p.lddk) || !al16(p.dv, p.lddv) || !al16(p.dq, p.lddq)) return false;
   // 32-bit byte offsets inside one batch element's rows (LDS-DMA voffset)
   if (p.Tq * p.ldq * 2 >= (1ll << 31) || p.Tk * p.ldk * 2 >= (1ll << 31) || p.Tq * p.ldo * 2 >= (1ll << 31)) return false;
   if (p.rate > 0.f && !p.keep) return false;
@@ -795,7 +797,7 @@ bool neurst_mha2_fwd_eligible(const Mha2FwdProblem& p) {
   if (!g_opt_mha_fused || p.dtype != NEURST_BF16 || (p.dh != 96 && p.dh != 64)) return false;
   if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
   if (p.B * p.H > 65535 * 16) return false;
-  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128)) return false;
+  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128 || p.B * p.H < 128)) return false;   // as the backward
   auto al16 = [](const void* x, int64_t ld) { return ((uintptr_t)x & 15) == 0 && (ld * 2) % 16 == 0; };
   if (!al16(p.q, p.ldq) || !al16(p.k, p.ldk) || !al16(p.v, p.ldv) || !al16(p.o, p.ldo)) return false;
   if ((p.bsq * 2) % 16 || (p.bsk * 2) % 16 || (p.bsv * 2) % 16 || (p.bso * 2) % 16) return false;

@@ -428,7 +428,11 @@ static bool launch_mfma(const bf16_t* src, const float* w, const float* bias, co
   const int64_t M = DX ? g.B * g.H * g.W : g.B * g.Ho * g.Wo;
   const int64_t ntiles = cdiv64(M, 16 * NWV);
   const int grid = (int)(ntiles < 256 ? ntiles : 256);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<NJ, NC, DX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // more than the 64 KiB default of dynamic LDS needs the attribute; refused -> the caller runs the general kernel
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<NJ, NC, DX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
   conv3x3_mfma_kernel<NJ, NC, DX><<<grid, NTH, lds, s>>>(src, w, bias, gamma, beta, d0, d1, mean, rstd, g);
   return true;
 }
@@ -438,6 +442,12 @@ static bool launch_gather(const bf16_t* x, const float* w, const float* bias, co
   constexpr size_t lds = mfma_lds_bytes<NJ, 1, false, true>();
   const int64_t ntiles = cdiv64(g.B * g.Ho * g.Wo, 16 * NWV);
   const int grid = (int)(ntiles < 1024 ? ntiles : 1024);       // 4 workgroups per CU: the kernel is all load latency and stores
+  static_assert(lds <= 160 * 1024, "LDS image of the weights does not fit");
+  // NJ = 8 (Cout = 128) needs ~79 KiB, above the 64 KiB default of dynamic LDS
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<NJ, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
   conv3x3_mfma_kernel<NJ, 1, false, true><<<grid, NTH, lds, s>>>(x, w, bias, gamma, beta, d0, d1, mean, rstd, g);
   return true;
 }
@@ -511,7 +521,10 @@ bool neurst_conv_dw_fast(const bf16_t* x, const bf16_t* dconv, float* dw, void* 
 #define CV_DW(km)                                                                                                          \
   do {                                                                                                                       \
     constexpr int lds = 16 * km * 64 * 4;                                                                                    \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(cv::conv_smallk_dw_kernel<km>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cv::conv_smallk_dw_kernel<km>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                               \
+      return false;                                                                                                          \
+    }                                                                                                                        \
     cv::conv_smallk_dw_kernel<km><<<grid, 1024, lds, s>>>(x, dconv, dw, g, K);                                               \
   } while (0)
     if (K <= 9) CV_DW(9); else if (K <= 27) CV_DW(27); else CV_DW(32);

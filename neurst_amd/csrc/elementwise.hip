@@ -14,7 +14,7 @@ void neurst_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* neurst_last_error(void) { return g_err; }
-extern "C" int neurst_abi_version(void) { return 1; }
+extern "C" int neurst_abi_version(void) { return NEURST_ABI_VERSION; }
 
 static inline int grid_for(int64_t n, int block, int per_thread = 1) {
   int64_t g = cdiv64(n, (int64_t)block * per_thread);

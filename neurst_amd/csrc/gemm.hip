@@ -741,11 +741,31 @@ extern "C" int neurst_gemm_wgrad_bias_grouped_tiles(int n, const void* const* A,
     gs[i].accumulate = 1; gs[i].split_k = 1; gs[i].opsum = opsum[i];
   }
   hipStream_t s = as_stream(stream);
-  if (ab_dtype == NEURST_BF16 && use_gemm256() && neurst_gemm256_group_launch(n, gs, tile_begin, tile_end, s)) {
+  // Eligibility for the grouped kernel is a PER-PROBLEM predicate (alignment, M % 8 / N % 8, 32-bit window, tile counts): a
+  // gradient whose tiles straddle two calls takes the same path in both, whatever else is queued beside it.  Eligible
+  // problems go out together in one grouped launch; an ineligible one is computed WHOLE by the call that holds its tile 0.
+  int ne = 0, emap[MAXP];
+  GemmArgs ge[MAXP];
+  int eb[MAXP], ee[MAXP];
+  for (int i = 0; i < n; ++i) {
+    if (!(ab_dtype == NEURST_BF16 && use_gemm256() && neurst_gemm256_group_eligible(gs[i]))) continue;
+    emap[ne] = i;
+    ge[ne] = gs[i];
+    eb[ne] = tile_begin ? tile_begin[i] : 0;
+    ee[ne] = tile_end ? tile_end[i] : (int)neurst_gemm256_group_tiles(M[i], N[i]);
+    ++ne;
+  }
+  bool grouped[MAXP] = {};
+  if (ne > 0) {
+    if (!neurst_gemm256_group_launch(ne, ge, eb, ee, s)) {
+      neurst_set_error("gemm_wgrad_bias_grouped: grouped launch refused an eligible problem");
+      return NEURST_E_INVALID;
+    }
     NEURST_CHECK_LAUNCH("gemm256_group");
-    return NEURST_OK;
+    for (int e = 0; e < ne; ++e) grouped[emap[e]] = true;
   }
   for (int i = 0; i < n; ++i) {                                // one launch per gradient (fp32 parity mode, odd shapes):
+    if (grouped[i]) continue;
     if (tile_begin && (tile_begin[i] != 0 || tile_end[i] == 0)) continue;   // whole, by the call that holds its first tile
     int rc;
     if (opsum[i]) rc = neurst_gemm_wgrad_bias(A[i], B[i], C[i], opsum[i], 1, M[i], N[i], K[i], lda[i], ldb[i], ldc[i], ab_dtype, 1, stream);

@@ -620,6 +620,14 @@ void neurst_gemm256_launch(const GemmArgs& g, int trans_a, int trans_b, int c_dt
 // window) - the caller then falls back to one launch per gradient.
 int neurst_gemm256_group_max() { return t2::MAX_GROUP; }
 int64_t neurst_gemm256_group_tiles(int64_t M, int64_t N) { return cdiv64(M, t2::BM) * cdiv64(N, 192); }
+// Per-problem predicate of the grouped kernel: alignment, whole 8-element chunks along both contiguous axes, 32-bit offsets
+// inside one (tile, K-tile) window, tile coordinates that fit the packed block id.
+bool neurst_gemm256_group_eligible(const GemmArgs& g) {
+  if (!g.a_aligned || !g.b_aligned || g.M % 8 || g.N % 8) return false;
+  if ((64 * g.lda + 256) * 2 >= 0x7fff0000ll || (64 * g.ldb + 256) * 2 >= 0x7fff0000ll) return false;
+  if (cdiv64(g.M, t2::BM) > 0xffff || cdiv64(g.N, 192) > 0x7fff) return false;
+  return true;
+}
 bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, const int* tile_begin, const int* tile_end, hipStream_t s) {
   if (n < 1 || n > t2::MAX_GROUP) return false;
   t2::GroupArgs ga;
@@ -627,12 +635,10 @@ bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, const int* tile_b
   int total = 0;
   for (int i = 0; i < n; ++i) {
     const GemmArgs& g = probs[i];
-    if (!g.a_aligned || !g.b_aligned || g.M % 8 || g.N % 8) return false;
-    if ((64 * g.lda + 256) * 2 >= 0x7fff0000ll || (64 * g.ldb + 256) * 2 >= 0x7fff0000ll) return false;
+    if (!neurst_gemm256_group_eligible(g)) return false;
     ga.gp[i] = g;
     ga.gp[i].tiles_m = (int)cdiv64(g.M, t2::BM);
     ga.gp[i].tiles_n = (int)cdiv64(g.N, 192);
-    if (ga.gp[i].tiles_m > 0xffff || ga.gp[i].tiles_n > 0x7fff) return false;
     ga.gp[i].split_k = 1;
     ga.nk[i] = (int)((cdiv64(g.K, t2::BK) + 1) / 2 * 2);
     const int all = ga.gp[i].tiles_m * ga.gp[i].tiles_n;

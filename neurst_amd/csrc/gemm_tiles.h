@@ -228,5 +228,6 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
 bool neurst_gemm256_eligible(const GemmArgs& g, int trans_a, int trans_b, bool c_f32);
 void neurst_gemm256_launch(const GemmArgs& g, int trans_a, int trans_b, int c_dtype, hipStream_t s);
 bool neurst_gemm256_group_launch(int n, const GemmArgs* probs, const int* tile_begin, const int* tile_end, hipStream_t s);
+bool neurst_gemm256_group_eligible(const GemmArgs& g);
 int neurst_gemm256_group_max();
 int64_t neurst_gemm256_group_tiles(int64_t M, int64_t N);

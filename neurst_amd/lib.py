@@ -60,6 +60,10 @@ def load():
         fn = getattr(lib, name)        # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    m = re.search(r'#define\s+NEURST_ABI_VERSION\s+(\d+)', open(HEADER).read())
+    want, got = int(m.group(1)), lib.neurst_abi_version()
+    if got != want:
+        raise NeurstLibError(f'{LIB_PATH} was built for ABI version {got}, include/neurst_hip.h declares {want}: rebuild the library')
     _lib = lib
     return lib
 

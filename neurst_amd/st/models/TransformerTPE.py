@@ -357,11 +357,16 @@ class TransformerTPE(Seq2SeqModel):
                 self._join_ctc_stream()
                 out4 = ops.loss_combine(xent, loss_ctc, mse_partial, mse_numel, B, xent.shape[1], w_ast, w_ctc, w_kd, self.device)
             g.tape = None
-        if self.frozen:               # frozen_scope filter (:171-183)
-            for p in self.store.vars.values():
-                if any(s in p.name for s in self.frozen):
-                    p.grad.zero_()
         return out4
+
+    def frozen_ranges(self):
+        """Arena ranges of the variables `frozen_scope` names (:171-183): the reference drops them from the list handed to
+        apply_gradients AFTER handle_gradients, so their gradients still count in the global norm, and neither the
+        variables nor their Adam slots ever change."""
+        if not self.frozen:
+            return []
+        al = G.ALIGN      # a variable owns its padding too: the ranges Adam still sees start on 256-byte boundaries
+        return [(p.offset, p.offset + -(-p.size // al) * al) for p in self.store.vars.values() if any(s in p.name for s in self.frozen)]
 
     def _step(self, batch):
         """forward + backward + gradient mean + Adam.  NEURST_OVERLAP_ADAM selects where the Adam kernel runs:
@@ -383,14 +388,15 @@ class TransformerTPE(Seq2SeqModel):
         try:
             out4 = self.forward_backward(batch)
             scale = average_gradients(self.bucketer)
-            scale = handle_gradients(self.args, self.store, scale)      # gradientTools.py:40-67, after the tower mean (TransformerTPE.py:167-168)
+            # gradientTools.py:40-67, after the tower mean and BEFORE the frozen-scope filter (TransformerTPE.py:167-183)
+            scale = handle_gradients(self.args, self.store, scale, produced=self.graph.produced)
         finally:
             self.bucketer.apply_fn = None
         if overlap:
             self.finish_update(self.store)
             self.last['lr'] = lr
         else:
-            self.last['lr'] = self.apply_gradients(self.store, scale)
+            self.last['lr'] = self.apply_gradients(self.store, scale, skip=self.frozen_ranges())
         return out4
 
     def train_step(self, batch):

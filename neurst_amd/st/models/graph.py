@@ -224,6 +224,7 @@ class Graph:
         self.name_counts = {}
         self.dropout_enabled = True
         self.on_param_grad = None   # callback(Param) once a parameter's gradient kernels are enqueued
+        self.produced = set()
         self.on_node_done = None    # callback() after every backward node (all its kernels are enqueued)
         # Weight gradients run on a second HIP stream beside the data-gradient chain: small layers cannot fill the chip on
         # their own, and for large ones each kernel's ramp-up and drain (~12 us per launch, measured) is covered by the
@@ -269,6 +270,8 @@ class Graph:
         self.name_counts = {}
         self.auto_site = 10_000
         self.tape = tape
+        if tape is not None:
+            self.produced = set()   # names of the variables whose gradient this step's backward produced
         if step is not None:
             self.step = step
 
@@ -288,6 +291,7 @@ class Graph:
         return float(r) if (self.dropout_enabled and r) else 0.0
 
     def param_grad_done(self, p):
+        self.produced.add(p.name)
         if self.on_param_grad is not None:
             self.on_param_grad(p)
 

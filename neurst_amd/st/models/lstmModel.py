@@ -58,9 +58,17 @@ class LSTM_Model(object):
         store.adam_t += 1
         self.global_step.value += 1
 
-    def apply_gradients(self, store, grad_scale):
-        """TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v update; theta -= lr_t*m/(sqrt(v)+eps); global_step += 1."""
+    def apply_gradients(self, store, grad_scale, skip=()):
+        """TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v update; theta -= lr_t*m/(sqrt(v)+eps); global_step += 1.
+        `skip`: arena ranges (start, end) of variables that are not handed to the optimizer (frozen_scope,
+        TransformerTPE.py:171-183): their values and Adam slots stay bit-identical."""
         lr, fn = self.optimizer_update_fn(store, grad_scale)
-        fn(0, store.total)
+        start = 0
+        for s, e in sorted(skip):
+            if s > start:
+                fn(start, s)
+            start = max(start, e)
+        if start < store.total:
+            fn(start, store.total)
         self.finish_update(store)
         return lr

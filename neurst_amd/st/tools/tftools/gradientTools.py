@@ -207,11 +207,13 @@ def average_gradients(bucketer):
     return bucketer.finish()
 
 
-def handle_gradients(args, store=None, scale=1.0):
+def handle_gradients(args, store=None, scale=1.0, produced=None):
     """gradientTools.py:40-67 on the averaged gradients (`scale` * the summed arena): L2 penalty on every variable without
     'bias' in its name (:47-48), tf.clip_by_global_norm (:60-65).  grad_clip_value / grad_clip_norm only touch variables
     with 'lstm' in their name (:51-56) - none of this model's - so they are accepted and change nothing.  Returns the
-    scale Adam has to apply (the clip factor rides on it).  Called without a store (graph construction): checks only."""
+    scale Adam has to apply (the clip factor rides on it).  Called without a store (graph construction): checks only.
+    `produced`: names of the variables whose gradient exists this step - the reference skips the penalty where `g is None`
+    (:48; such a variable is then not updated at all); None = every variable has one."""
     lam = float(args.lambda_l2 or 0.0)
     clip = float(args.grad_clip_global_norm or 0.0)
     if lam < 0 or clip < 0:
@@ -221,7 +223,7 @@ def handle_gradients(args, store=None, scale=1.0):
     from .... import ops
     if lam > 0.0:
         for p in store.vars.values():
-            if 'bias' not in p.name:
+            if 'bias' not in p.name and (produced is None or p.name in produced):
                 # scale * (g + (lam / scale) v) = scale * g + lam * v
                 ops.axpy_f32(store.grads[p.offset:p.offset + p.size], store.params[p.offset:p.offset + p.size], lam / scale)
     if clip > 0.0:

@@ -602,15 +602,21 @@ def handle_gradients(grads, P, lambda_l2=0.0, grad_clip_global_norm=0.0):
 
 
 def train_step(model: OracleTPE, P, M, V, batch, global_step, warmup_steps, peak, decay_steps, specaug_params=None, lambda_l2=0.0,
-               grad_clip_global_norm=0.0):
+               grad_clip_global_norm=0.0, frozen_scope=None):
     """One optimisation step: lr from the pre-increment global_step (run_lut.py:346), handle_gradients (TransformerTPE.py:167-168),
-    TF Adam with beta1=.9, beta2=.98, eps=1e-9 hard-coded (lstmModel.py:526-530)."""
+    then the frozen-scope filter (TransformerTPE.py:170-183: variables whose name contains one of the comma-separated
+    strings are dropped from the list given to apply_gradients - AFTER handle_gradients, so their gradients still count in
+    the global norm - and neither they nor their Adam slots change), TF Adam with beta1=.9, beta2=.98, eps=1e-9 hard-coded
+    (lstmModel.py:526-530)."""
     model.step = global_step
     out = model.loss_and_grads(P, batch, specaug_params)
     if lambda_l2 or grad_clip_global_norm:
         out['grads'] = handle_gradients(out['grads'], P, lambda_l2, grad_clip_global_norm)
     lr = ops.warmup_exponential_decay(global_step, warmup_steps, peak, 0.5, decay_steps)
     t = global_step + 1
+    frozen = [f for f in str(frozen_scope).split(',') if f] if frozen_scope else []
     for k in P:
+        if any(f in k for f in frozen):
+            continue
         P[k], M[k], V[k] = ops.adam_step(P[k], out['grads'][k], M[k], V[k], lr, t)
     return out, lr

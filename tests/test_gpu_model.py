@@ -296,6 +296,49 @@ def test_l2_penalty_and_global_norm_clip_follow_the_oracle():
             assert np.abs(Pd[k] - P[k])[sel].max() < 2e-4 * max(np.abs(P[k]).max(), 1e-3), k
 
 
+def test_frozen_scope_is_filtered_after_handle_gradients():
+    """frozen_scope (TransformerTPE.py:170-183) with the L2 penalty and the global-norm clip on: the frozen variables and
+    their Adam slots (pre-loaded with non-zero moments, as after a restore) stay BIT-identical over three steps, their
+    gradients still count in the clip's norm, and every other variable follows the oracle."""
+    args = ge.tiny_args(compute_dtype='fp32')
+    args.lambda_l2, args.grad_clip_global_norm = 0.05, 0.25
+    args.frozen_scope = 'TPEncoder,embedding'
+    model = make_model(args, step=0)
+    assert model.frozen == ['TPEncoder', 'embedding']
+    P = {k: v.astype(np.float64) for k, v in perturb(model).items()}
+    rng = np.random.default_rng(5)
+    M = {k: 0.01 * rng.standard_normal(v.shape) for k, v in P.items()}
+    V = {k: 1e-4 * rng.random(v.shape) for k, v in P.items()}
+    model.store.load_slots(M, V)
+    frozen = [k for k in P if 'TPEncoder' in k or 'embedding' in k]
+    assert frozen and len(frozen) < len(P)
+    P0, M0, V0 = model.store.export(), model.store.export(model.store.m), model.store.export(model.store.v)
+    M = {k: M0[k].astype(np.float64) for k in P}                 # the fp32 values the device holds
+    V = {k: V0[k].astype(np.float64) for k in P}
+    cfg = ge.oracle_cfg_from_args(args).zero_dropout()
+    orc = OracleTPE(cfg, is_train=True, dropout=False)
+    batch = make_batch(B=2, Traw=24, V=11, L=5, U=3, Lb=4, bert_dim=16, dim_raw=4, seed=1)
+    ob = oracle_batch(batch)
+    for step in range(3):
+        loss = model.train_step(batch)[0]
+        out, lr = oracle_train_step(orc, P, M, V, ob, step, args.warmup_steps, args.peak, args.decay_steps, lambda_l2=0.05,
+                                    grad_clip_global_norm=0.25, frozen_scope=args.frozen_scope)
+        assert abs(loss - out['loss']) < 3e-5 * abs(out['loss']), (step, loss, out['loss'])
+        if step == 0:                                            # the frozen gradients are a real share of the norm
+            gf = np.sqrt(sum(float((out['grads'][k] ** 2).sum()) for k in frozen))
+            ga = np.sqrt(sum(float((g ** 2).sum()) for g in out['grads'].values()))
+            assert gf > 0.05 * ga
+    Pd, Md, Vd = model.store.export(), model.store.export(model.store.m), model.store.export(model.store.v)
+    for k in frozen:
+        assert np.array_equal(Pd[k], P0[k]) and np.array_equal(Md[k], M0[k]) and np.array_equal(Vd[k], V0[k]), k
+    for k in P:
+        if k in frozen:
+            continue
+        assert np.abs(Md[k] - M[k]).max() < 2e-4 * max(np.abs(M[k]).max(), 1e-6), k
+        assert np.abs(Pd[k] - P[k]).max() < 2e-4 * max(np.abs(P[k]).max(), 1e-3), k
+    assert model.graph.produced == set(P)                        # every variable of the LUT graph receives a gradient
+
+
 def test_train_and_infer_models_share_variables():
     args = ge.tiny_args(compute_dtype='fp32')
     train = make_model(args)

@@ -301,6 +301,36 @@ def test_grouped_weight_gradients_as_a_tile_queue():
         ops.gemm_wgrad_grouped(probs[:1], [(0, 37)])
 
 
+@pytest.mark.parametrize('mode', ['misaligned_neighbour', 'gemm256_off'])
+def test_grouped_tile_queue_with_problems_the_tile_kernel_cannot_take(mode):
+    """Eligibility for the grouped kernel is decided per problem: a gradient that straddles two calls is computed exactly
+    once whether or not a neighbour in one of the calls is ineligible (M % 8 != 0 -> its own launch, whole, by the call that
+    holds its tile 0), and with the 256-tile kernel switched off every problem falls back the same way in every call."""
+    from neurst_amd import lib
+    Clib = lib.load()
+    rng = np.random.default_rng(23)
+    shapes = [(768, 768), (2304, 768), (100, 72), (776, 520)]        # problem 2: M % 8 != 0 - never eligible
+    K = 520
+    ins = [(bf16_round(rng.standard_normal((K, M)) * 0.1), bf16_round(rng.standard_normal((K, N)) * 0.1)) for M, N in shapes]
+    refs = [(a.T.astype(np.float64) @ b + 1.0, a.astype(np.float64).sum(0) + 2.0) for a, b in ins]
+    probs = [(dev(a, torch.bfloat16), dev(b, torch.bfloat16), torch.ones((a.shape[1], b.shape[1]), dtype=torch.float32, device=DEV),
+              torch.full((a.shape[1],), 2.0, dtype=torch.float32, device=DEV)) for a, b in ins]
+    tiles = [ops.wgrad_group_tiles(M, N) for M, N in shapes]
+    try:
+        if mode == 'gemm256_off':
+            assert Clib.neurst_set_option(b'gemm256', 0) == 0
+        # call 1: problem 0 whole, the first 20 tiles of problem 1; call 2: the rest of problem 1 BESIDE the ineligible
+        # problem 2 and problem 3; call 3: an empty range of problem 2 (its tile 0 is not in it: nothing may happen)
+        ops.gemm_wgrad_grouped([probs[0], probs[1]], [(0, tiles[0]), (0, 20)])
+        ops.gemm_wgrad_grouped([probs[1], probs[2], probs[3]], [(20, tiles[1]), (0, tiles[2]), (0, tiles[3])])
+        ops.gemm_wgrad_grouped([probs[2]], [(tiles[2], tiles[2])])
+    finally:
+        assert Clib.neurst_set_option(b'gemm256', 1) == 0
+    for (_, _, C, s), (rc, rs) in zip(probs, refs):
+        assert relerr(host(C), rc) < 1e-5
+        assert relerr(host(s), rs) < 1e-5
+
+
 def test_set_option_rejects_unknown_names():
     from neurst_amd import lib
     C = lib.load()
@@ -670,7 +700,8 @@ def test_conv_ln_relu_and_maxpool():
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,stride', [(13, 10, 64, 64, (2, 2)), (9, 12, 32, 64, (2, 2)), (11, 7, 64, 32, (1, 1)), (10, 9, 32, 32, (2, 1)),
-                                                 (13, 10, 1, 64, (2, 2)), (12, 11, 3, 64, (2, 2)), (7, 9, 3, 40, (1, 2))])
+                                                 (13, 10, 1, 64, (2, 2)), (12, 11, 3, 64, (2, 2)), (7, 9, 3, 40, (1, 2)),
+                                                 (11, 10, 1, 32, (2, 2)), (9, 13, 3, 128, (2, 2))])
 def test_conv_bf16_fast_paths_against_oracle(H, W, Cin, Cout, stride):
     """bf16 layers: implicit-GEMM MFMA kernels (3x3, Cin % 32 == 0: forward and data gradient), im2col + GEMM weight gradient,
     the registers-resident first-layer kernels (kh kw Cin <= 32) and the 16-byte-lane LN backward, against the oracle on operands

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = lib.load()
     for name in protos:
         assert hasattr(L, name), name
-    assert L.neurst_abi_version() == 1
+    assert L.neurst_abi_version() == 3      # == NEURST_ABI_VERSION of include/neurst_hip.h (lib.load() checks the pair)
     # argument validation happens on the host before any launch: callable without a GPU
     assert L.neurst_gemm_bias_act(0, 0, 0, 0, 0, 4, 4, 4, 4, 4, 4, 0, 1, 0, 0, 0, 0, 1, 0) == -1
     assert b'null' in L.neurst_last_error()
@@ -240,8 +240,9 @@ def test_checkpoint_roundtrip_rename_and_average(tmp_path, fmt):
 
 @pytest.mark.parametrize('t_steps,b1,b2,want', [(8, None, None, 8), (1200, 0.0, None, 1200), (1200, 0.0, 'exact', 1200), (50000, 0.0, 0.0, 50000),
                                                (300, 'exact', None, 300)])
-def test_restore_of_a_tensorflow_written_checkpoint_recovers_adam_step(tmp_path, t_steps, b1, b2, want):
-    """A TF checkpoint has no adam_t, only beta1_power = 0.9^(t+1) and beta2_power = 0.98^(t+1) in fp32; beta1_power is
+def test_restore_of_a_bundle_without_adam_t_recovers_the_step_from_the_beta_powers(tmp_path, t_steps, b1, b2, want):
+    """(The bundle is written by this repository's own writer with the variables TensorFlow's Saver would store - no
+    TensorFlow-written file exists here.)  A TF checkpoint has no adam_t, only beta1_power = 0.9^(t+1) and beta2_power = 0.98^(t+1) in fp32; beta1_power is
     exactly 0.0 after ~1000 steps (log(0) used to raise OverflowError in restore), beta2_power after ~5000."""
     import torch
     from neurst_amd import ops
@@ -335,6 +336,112 @@ def test_tensor_bundle_container(tmp_path):
     footer = TB._put_varint(off_meta) + TB._put_varint(len(metab)) + TB._put_varint(off_idx) + TB._put_varint(len(idxb))
     open(str(tmp_path / 'snappy.index'), 'wb').write(body + footer + bytes(40 - len(footer)) + struct.pack('<Q', TB.MAGIC))
     assert TB.read_table(str(tmp_path / 'snappy.index')) == [(b'', b'\x08\x01'), (b'aa', b'v1'), (b'ab', b'v2')]
+
+
+def _bundle_tensors(rng):
+    t = {'transformer/encoder/block_%d/ff_hidden/dense/kernel' % i: rng.standard_normal((7, 5)).astype(np.float32) for i in range(120)}
+    t.update({'transformer/encoder/block_%d/layer_norm/layer_norm_scale' % i: rng.standard_normal(6).astype(np.float32) for i in range(40)})
+    t.update({'global_step': np.int64(4321), 'beta1_power': np.float32(0.9 ** 8), 'x/empty': np.zeros((0, 3), np.float32),
+              'x/i32': np.arange(6, dtype=np.int32).reshape(2, 3), 'x/f64': rng.standard_normal(3), 'x/bool': np.array([True, False]),
+              'x/u8': np.arange(5, dtype=np.uint8), 'x/f16': rng.standard_normal((2, 2)).astype(np.float16)})
+    return t
+
+
+@pytest.mark.parametrize('block_size,restart,compress', [(262144, 16, False), (512, 16, False), (300, 3, False), (4096, 16, True), (700, 1, True)])
+def test_bundle_reader_against_the_independent_oracle_writer(tmp_path, block_size, restart, compress):
+    """f1, reader side: tensorBundle.BundleReader / checkpointTools read files written by oracle/bundle.py - a restatement
+    of TensorFlow's TableBuilder + BundleWriter by other means (google.protobuf messages, table-driven CRC, shortest-separator
+    index keys) - in TF's own geometry (one 256 KiB block, restart interval 16) and in geometries that force many blocks,
+    short restart runs and snappy-compressed blocks; values, dtypes and shapes must come back exactly, bfloat16 widened."""
+    from oracle import bundle as OB
+    from neurst_amd.st.tools.tftools import checkpointTools as ck
+    from neurst_amd.st.tools.tftools import tensorBundle as TB
+    rng = np.random.default_rng(block_size + restart)
+    t = _bundle_tensors(rng)
+    bf = rng.standard_normal((3, 4)).astype(np.float32)
+    bf = (bf.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    prefix = str(tmp_path / 'model-7')
+    OB.write_bundle(prefix, dict(t, **{'x/bf16': (bf, 'bfloat16')}), block_size=block_size, restart_interval=restart, compress=compress)
+    tab = OB.Table(prefix + '.index')
+    if block_size < 1000:
+        assert tab.num_blocks() > 5
+    if compress:                                                 # at least one block really is stored compressed
+        kinds = []
+        for _, h in tab.index:
+            off, p = OB.unvarint(h, 0)
+            size, _ = OB.unvarint(h, p)
+            kinds.append(tab.buf[off + size])
+        assert 1 in kinds
+    r = TB.BundleReader(prefix)
+    assert sorted(r.entries) == sorted(list(t) + ['x/bf16'])
+    for k, v in t.items():
+        g = r.get_tensor(k)
+        assert g.dtype == np.asarray(v).dtype and g.shape == np.asarray(v).shape and np.array_equal(g, v), k
+    assert np.array_equal(r.get_tensor('x/bf16'), bf)
+    assert int(ck.load_variable(prefix, 'global_step')) == 4321
+    assert dict(ck.list_variables(prefix))['x/i32'] == [2, 3]
+
+
+def test_bundle_writer_against_the_independent_oracle_reader(tmp_path):
+    """f1, writer side: what tensorBundle.write_bundle / checkpointTools.save_checkpoint(fmt='tf') write is opened by the
+    oracle's reader the way TensorFlow's BundleReader does it - footer, index-block Seek, restart-array binary search,
+    every block and tensor CRC recomputed from the polynomial, messages parsed by google.protobuf - tensor by tensor."""
+    import torch
+    from oracle import bundle as OB
+    from neurst_amd import ops
+    from neurst_amd.st.models.graph import VariableStore
+    from neurst_amd.st.tools.tftools import checkpointTools as ck
+    from neurst_amd.st.tools.tftools import tensorBundle as TB
+    rng = np.random.default_rng(3)
+    t = _bundle_tensors(rng)
+    prefix = str(tmp_path / 'model-9')
+    TB.write_bundle(prefix, t)
+    r = OB.Reader(prefix)
+    assert r.header.num_shards == 1 and r.header.endianness == 0 and r.header.version.producer == 1
+    assert r.table.num_blocks() > 1                              # the product writes 4 KiB blocks: lookups cross the index block
+    assert sorted(r.names()) == sorted(t)
+    for k, v in t.items():
+        g = r.tensor(k)
+        assert g.dtype == np.asarray(v).dtype and g.shape == np.asarray(v).shape and np.array_equal(g, v), k
+        e = r.entry(k)
+        assert e.shard_id == 0 and e.size == np.asarray(v).nbytes and e.HasField('shape')
+    assert r.table.get(b'no/such/tensor') is None and r.table.get(b'zzzz') is None
+    # a model checkpoint under the TF names, through the checkpoint interface
+    specs = [('transformer/embedding', (11, 4), 'glorot'), ('transformer/encoder/encoder_fc/kernel', (6, 4), 'glorot'),
+             ('transformer/encoder/block_0/layer_norm/layer_norm_scale', (4,), 'ones')]
+    a = VariableStore(specs, torch.device('cpu'), ops.F32, seed=3)
+    a.m += 0.25
+    a.v += 0.5
+    a.adam_t = 17
+    p = ck.save_checkpoint(str(tmp_path / 'model-17'), a, 17, fmt='tf')
+    r = OB.Reader(p)
+    P, M, V = a.export(), a.export(a.m), a.export(a.v)
+    for k in P:
+        assert np.array_equal(r.tensor(k), P[k]) and np.array_equal(r.tensor(k + '/Adam'), M[k]) and np.array_equal(r.tensor(k + '/Adam_1'), V[k]), k
+    assert int(r.tensor('global_step')) == 17 and r.tensor('global_step').shape == ()
+    assert abs(float(r.tensor('beta1_power')) - 0.9 ** 18) < 1e-6 and abs(float(r.tensor('beta2_power')) - 0.98 ** 18) < 1e-6
+
+
+def test_oracle_bundle_codecs_known_answers():
+    """pins of the oracle's own pieces: CRC-32C (RFC 3720 B.4), the mask constant, snappy elements from the format
+    description, separator / successor keys as table_builder.cc documents them, and the two snappy decoders on each
+    other's input."""
+    from oracle import bundle as OB
+    from neurst_amd.st.tools.tftools import tensorBundle as TB
+    assert OB.crc32c(bytes(32)) == 0x8A9136AA and OB.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert OB.crc32c(bytes(range(32))) == 0x46DD794E and OB.crc32c(b'123456789') == 0xE3069283
+    assert OB.crc32c(b'6789', OB.crc32c(b'12345')) == 0xE3069283                      # Extend
+    for blob in (b'', b'abc', bytes(range(200))):
+        assert OB.mask(OB.crc32c(blob)) == TB._crc(blob)
+    assert OB.snappy_decompress(bytes([11, 0x0c]) + b'abcd' + bytes([((7 - 4) << 2) | 1, 4])) == b'abcdabcdabc'
+    rng = np.random.default_rng(0)
+    for blob in (b'', b'a', b'abcd' * 500, bytes(rng.integers(0, 4, 5000, dtype=np.uint8)), bytes(rng.integers(0, 256, 3000, dtype=np.uint8)),
+                 b'transformer/encoder/block_0/' * 40 + bytes(300)):
+        z = OB.snappy_compress(blob)
+        assert OB.snappy_decompress(z) == blob and TB._snappy_decompress(z) == blob
+    assert len(OB.snappy_compress(b'abcd' * 500)) < 120
+    assert OB.shortest_separator(b'abc1xyz', b'abc5') == b'abc2' and OB.shortest_separator(b'abc', b'abcd') == b'abc'
+    assert OB.shortest_separator(b'ab\xffz', b'ac') == b'ab\xffz' and OB.short_successor(b'\xff\xffa9') == b'\xff\xffb'
 
 
 def test_avg_checkpoints_cli(tmp_path):
