@@ -85,19 +85,27 @@ template <int DH> struct Lds {
   static constexpr int QS0 = KIMG + KIMG_B, SLICE_B = QS * ROWB;
   static constexpr int DO0 = QS0 + 2 * SLICE_B;
   static constexpr int DST0 = DO0 + 2 * SLICE_B, DST_B = KB * 64;
-  static constexpr int KW0 = DST0 + 2 * DST_B;            // [4 waves][2 blk][32 q] u32
-  static constexpr int STAT0 = KW0 + 4 * 2 * 32 * 4;      // lse2 [Tqp], delta [Tqp]
+  static constexpr int KW0 = DST0 + 2 * DST_B;            // [waves][key columns per wave][32 q] u32 = one word per key column of the block
+  static constexpr int STAT0 = KW0 + (KB / 32) * 32 * 4;  // lse2 [Tqp], delta [Tqp]
+  static constexpr int STG_ROWB = ROWB + 16;              // row pitch of the dK / dV store staging (208 / 144 B: the 8-byte column writes of
+                                                          // a 192-B pitch land on two bank positions, 8-way)
+  static_assert(KB * STG_ROWB <= DST0, "store staging overruns the K image + slice buffers");
   static int bytes(int tqp) { return STAT0 + 2 * tqp * 4; }
 };
 
-template <int DH, bool DROP, bool STAMPS>
-__global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
+// NW = waves per workgroup: 4 (one per SIMD, 64 keys each) or 8 (two per SIMD, 32 keys each: one wave's exp / dropout /
+// pack work runs under its partner's MFMA chains; 96 accumulator registers per wave instead of 192)
+template <int DH, bool DROP, bool STAMPS, int NW>
+__global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
   typedef Lds<DH> L;
   constexpr int ROWB = DH * 2;      // row pitch of the LDS images (the LDS-DMA writes rows back to back)
   constexpr int KS = DH / 16;       // k-steps of a product over d (32x32x16)
   constexpr int DB = DH / 32;       // 32-wide d blocks of dK^T / dV^T
-  constexpr int NT = DH / 32;       // 16-wide d blocks of dQ per wave (DH/16 blocks over the two wave pairs)
+  constexpr int NT = NW == 4 ? DH / 32 : 2;   // most 16-wide d blocks of dQ a wave computes (DH / 16 blocks x two query halves over the waves)
   constexpr int CH = DH / 8;
+  constexpr int NTHR = NW * 64;
+  constexpr int KPW = KB / NW;      // keys per wave: 64 or 32
+  constexpr int NBLK = KPW / 32;    // 32-key MFMA columns per wave
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, g = lane >> 5;
   const int G = lane >> 4, qq = (lane & 15) >> 2, p4 = lane & 3;
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   const int nslice = (Tq + QS - 1) / QS, tqp = nslice * QS;
   float* lse2_s = reinterpret_cast<float*>(smem + L::STAT0);
   float* del_s = lse2_s + tqp;
-  uint32_t* kw_s = reinterpret_cast<uint32_t*>(smem + L::KW0) + w * 64;
+  uint32_t* kw_s = reinterpret_cast<uint32_t*>(smem + L::KW0) + w * (32 * NBLK);
   typedef __attribute__((address_space(3))) char* lds_cp;
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_cp)smem;            // LDS byte address of the dynamic segment
 
@@ -129,32 +137,6 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   };
   stamp();
 
-  // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O).  Four lanes per
-  // row (chunks p4, p4 + 4, ...: 64 contiguous bytes per row and instruction), quad sum by DPP.  (Streaming them one
-  // slice ahead inside the first pass instead was measured: the burst only moves into the loop, no gain.)
-  for (int q0 = 0; q0 < tqp; q0 += 64) {
-    const int q = q0 + (tid >> 2);
-    float d = 0.f;
-    if (q < Tq) {
-      const bf16x8* po = reinterpret_cast<const bf16x8*>(og + (int64_t)q * a.ldo);
-      const bf16x8* pd = reinterpret_cast<const bf16x8*>(dog + (int64_t)q * a.ldo);
-#pragma unroll
-      for (int i = 0; i < CH / 4; ++i) {
-        const bf16x8 x = po[p4 + 4 * i], y = pd[p4 + 4 * i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
-      }
-    }
-    d += NEURST_DPP_F32(d, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-    d += NEURST_DPP_F32(d, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-    if (p4 == 0 && q < tqp) {
-      float l2 = INFINITY;
-      if (q < Tq) { l2 = a.lse[(int64_t)bh * Tq + q] * unit; a.delta[(int64_t)bh * Tq + q] = d; }
-      lse2_s[q] = l2;
-      del_s[q] = d;
-    }
-  }
-
   const u32x4 rs_q = make_rsrc(qg, (unsigned)(((int64_t)(Tq - 1) * a.ldq + DH) * 2));
   const u32x4 rs_do = make_rsrc(dog, (unsigned)(((int64_t)(Tq - 1) * a.ldo + DH) * 2));
   const u32x4 rs_k = make_rsrc(kg, (unsigned)(((int64_t)(Tk - 1) * a.ldk + DH) * 2));
@@ -166,22 +148,23 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
     asm volatile("" : "+v"(t));      // recomputed per call (a few VALU ops): as loop invariants these offsets get spilled, and a
                                      // scratch reload's vmcnt(0) then waits for the DMA issued just before it
 #pragma unroll
-    for (int i = 0; i < (QS * CH + 255) / 256; ++i) {
-      if (64 * (w + 4 * i) < QS * CH) {                                   // wave-uniform
-        const int n = t + 256 * i, row = n / CH, ch = (n - row * CH) ^ ((row >> 2) & 3);
+    for (int i = 0; i < (QS * CH + NTHR - 1) / NTHR; ++i) {
+      if (64 * (w + NW * i) < QS * CH) {                                  // wave-uniform
+        const int n = t + NTHR * i, row = n / CH, ch = (n - row * CH) ^ ((row >> 2) & 3);
         const int qrow = sl * QS + row;
-        const unsigned dst = (unsigned)(w + 4 * i) * 1024u;
+        const unsigned dst = (unsigned)(w + NW * i) * 1024u;
         dma16(rs_q, lds_base + L::QS0 + buf * L::SLICE_B + dst, qrow * ldq2 + ch * 16);
         dma16(rs_do, lds_base + L::DO0 + buf * L::SLICE_B + dst, qrow * ldo2 + ch * 16);
       }
     }
   };
-  // keep words of slice sl for this wave's two key columns: lane (c, g) fetches word g of query sl * 32 + c (zero beyond the tensor)
+  // keep words of slice sl for this wave's key columns: lane (c, g) fetches word g of query sl * 32 + c (zero beyond the tensor;
+  // with one key column per wave the upper half-wave fetches nothing)
   auto load_kw = [&](int sl, int kb) -> uint32_t {
     uint32_t r = 0u;
     if constexpr (DROP) {
-      const int q = sl * QS + c, wi = kb * (KB / 32) + 2 * w + g;
-      const bool ok = q < Tq && wi < a.nw;
+      const int q = sl * QS + c, wi = kb * (KB / 32) + NBLK * w + g;
+      const bool ok = q < Tq && wi < a.nw && g < NBLK;
       const uint32_t* pw = a.keep + ((int64_t)bh * Tq + (ok ? q : 0)) * a.nw + (ok ? wi : 0);
       r = *pw;
       r = ok ? r : 0u;
@@ -189,7 +172,12 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
     return r;
   };
 
-  const int dq_qh = w & 1, dq_d0 = (w >> 1) * (NT * 16);                  // this wave's part of a dQ slice: 16 queries x NT*16 columns
+  // this wave's part of a dQ slice: 16 queries (half dq_qh) x ntw 16-wide d blocks from column dq_d0.  Four waves: DH / 32
+  // blocks each.  Eight waves, DH = 96 (12 tiles): waves 0-3 take two blocks (columns 0..63), waves 4-7 one (64..95);
+  // DH = 64 (8 tiles): one each.
+  const int dq_qh = w & 1;
+  const int ntw = NW == 4 ? NT : (DH == 96 && w < 4 ? 2 : 1);
+  const int dq_d0 = NW == 4 ? (w >> 1) * (NT * 16) : (DH == 96 ? (w < 4 ? (w >> 1) * 32 : 64 + ((w - 4) >> 1) * 16) : (w >> 1) * 16);
 
   // ---- lane constants of the LDS addressing; every read below is one of these plus a compile-time offset
   // row reads (b128) of a [row][192 B] image, row = 32 m + c, chunk 2 ks + g = 4 (ks >> 1) + (2 (ks & 1) + g)
@@ -204,42 +192,96 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   int trk_lo[NT], trk_hi[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    trk_lo[n] = img_off<ROWB>(8 * G + qq, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
-    trk_hi[n] = img_off<ROWB>(8 * G + qq + 4, dq_d0 / 8 + 2 * n + (p4 >> 1)) + 8 * (p4 & 1);
+    // (a wave with fewer than NT blocks of its own multiplies its last block once more - uniform code, the result is dropped)
+    const int nb = n < ntw ? n : ntw - 1;
+    trk_lo[n] = img_off<ROWB>(8 * G + qq, dq_d0 / 8 + 2 * nb + (p4 >> 1)) + 8 * (p4 & 1);
+    trk_hi[n] = img_off<ROWB>(8 * G + qq + 4, dq_d0 / 8 + 2 * nb + (p4 >> 1)) + 8 * (p4 & 1);
   }
-  // dS^T stores: key row 64 w + 32 blk + c, slot 2 j + g
-  const int krow = 64 * w + c;
+  // dS^T stores: key row KPW w + 32 blk + c, slot 2 j + g
+  const int krow = KPW * w + c;
+
+  // K image of a key block by LDS-DMA (offsets from an opaque copy of the thread index: kept as loop invariants they are
+  // spilled, and each reload's vmcnt(0) waits for the DMA piece issued just before it - the pieces would go out one by one)
+  auto issue_kimage = [&](int kb) __attribute__((always_inline)) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int i = 0; i < KB * CH / NTHR; ++i) {
+      const int n = t + NTHR * i, row = n / CH, ch = (n - row * CH) ^ ((row >> 2) & 3);
+      dma16(rs_k, lds_base + L::KIMG + (unsigned)(w + NW * i) * 1024u, (int)((kb * KB + row) * a.ldk * 2 + ch * 16));
+    }
+  };
+  // the first block's K image and query slice are on their way while the statistics below are computed
+  issue_kimage(0);
+  issue_slice(0);
+
+  // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O).  Four lanes per
+  // row (chunks p4, p4 + 4, ...: 64 contiguous bytes per row and instruction), quad sum by DPP.  (Streaming them one
+  // slice ahead inside the first pass instead was measured: the burst only moves into the loop, no gain.)
+  // Four row groups per iteration, every load issued before the first sum: one memory latency per iteration instead of four.
+  {
+    constexpr int RPI = NTHR / 4;                                          // rows per group
+    for (int q0 = 0; q0 < tqp; q0 += 4 * RPI) {
+      bf16x8 x[4][CH / 4], y[4][CH / 4];
+      float l2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * RPI + (tid >> 2);
+        const int qc = q < Tq ? q : Tq - 1;
+        const bf16x8* po = reinterpret_cast<const bf16x8*>(og + (int64_t)qc * a.ldo);
+        const bf16x8* pd = reinterpret_cast<const bf16x8*>(dog + (int64_t)qc * a.ldo);
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i) { x[u][i] = po[p4 + 4 * i]; y[u][i] = pd[p4 + 4 * i]; }
+        l2[u] = a.lse[(int64_t)bh * Tq + qc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * RPI + (tid >> 2);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d += (float)x[u][i][j] * (float)y[u][i][j];
+        d += NEURST_DPP_F32(d, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+        d += NEURST_DPP_F32(d, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+        if (p4 == 0 && q < tqp) {
+          if (q < Tq) a.delta[(int64_t)bh * Tq + q] = d;
+          lse2_s[q] = q < Tq ? l2[u] * unit : INFINITY;
+          del_s[q] = q < Tq ? d : 0.f;
+        }
+      }
+    }
+  }
 
   for (int kb = 0; kb < nkb; ++kb) {
     const int K0 = kb * KB;
-    __syncthreads();                                                      // previous pass has left the K image and the staging buffers
-    stamp();
-    // ---- K image of the block by LDS-DMA
-#pragma unroll
-    for (int i = 0; i < KB * CH / 256; ++i) {
-      const int n = tid + 256 * i, row = n / CH, ch = (n % CH) ^ ((row >> 2) & 3);
-      dma16(rs_k, lds_base + L::KIMG + (unsigned)(w + 4 * i) * 1024u, (int)((K0 + row) * a.ldk * 2 + ch * 16));
+    if (kb > 0) {
+      __syncthreads();                                                    // previous pass has left the K image and the staging buffers
+      issue_kimage(kb);
+      issue_slice(0);
     }
-    issue_slice(0);
-    // ---- V fragments of this wave's 64 keys (B operands: column = key, k = 16 ks + 8 g + j); K fragments come from the image
-    bf16x8 vf[2][KS];
-    float kbias[2];
+    stamp();
+    int tk = tid;
+    asm volatile("" : "+v"(tk));
+    // ---- V fragments of this wave's keys (B operands: column = key, k = 16 ks + 8 g + j); K fragments come from the image
+    bf16x8 vf[NBLK][KS];
+    float kbias[NBLK];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const int key = K0 + 64 * w + 32 * blk + c;
+    for (int blk = 0; blk < NBLK; ++blk) {
+      const int key = K0 + KPW * w + 32 * blk + (tk & 31);
       const bool ok = key < Tk;
       const int kc = ok ? key : Tk - 1;
       const bf16x8 zero = {};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vg + (int64_t)kc * a.ldv + 16 * ks + 8 * g);
+        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vg + (int64_t)kc * a.ldv + 16 * ks + 8 * ((tk >> 5) & 1));
         vf[blk][ks] = ok ? vv : zero;
       }
       kbias[blk] = !ok ? -INFINITY : ((a.keypad && key >= len) ? NEG_BIAS * unit : 0.f);
     }
-    f32x16 dk[2][DB], dv[2][DB];
+    f32x16 dk[NBLK][DB], dv[NBLK][DB];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
+    for (int blk = 0; blk < NBLK; ++blk)
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -260,13 +302,20 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
     };
     // the partial sums of the earlier passes: loaded FIRST in an iteration (older than the DMA pieces issued after them, so
     // the wait for them leaves those in flight) and added after the last k-step
+    // (addresses from an opaque copy of the lane index: as loop invariants the compiler keeps a 64-bit pointer per store in
+    // scratch, and every reload's s_waitcnt vmcnt(0) then waits for the store issued just before it - one HBM round trip
+    // per store instruction instead of one per group)
     auto dq_load_partial = [&](int sl) __attribute__((always_inline)) {
-      const int q_base = sl * QS + 16 * dq_qh + 4 * G;                   // + r: the four queries of this lane's accumulator registers
-      const float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (lane & 15);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int q_base = sl * QS + 16 * dq_qh + 4 * (ln >> 4);           // + r: the four queries of this lane's accumulator registers
+      const float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (ln & 15);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
+        if (n < ntw) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dqw[n][r] = wsp[r * DH + 16 * n];
+          for (int r = 0; r < 4; ++r) dqw[n][r] = wsp[r * DH + 16 * n];
+        }
     };
     auto dq_begin = [&](int sl) __attribute__((always_inline)) {
 #pragma unroll
@@ -279,31 +328,39 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       for (int n = 0; n < NT; ++n) dqa[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dq_af[kk & 1], dq_bf[kk & 1][n], dqa[n], 0, 0, 0);
     };
     auto dq_end = [&](int sl) __attribute__((always_inline)) {
-      const int q_base = sl * QS + 16 * dq_qh + 4 * G;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int q_base = sl * QS + 16 * dq_qh + 4 * (ln >> 4);
       if (!first) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) dqa[n] += dqw[n];
       }
       if (last) {
-        bf16_t* dqp = a.dq + ((int64_t)b * Tq + q_base) * a.lddq + h * DH + dq_d0 + (lane & 15);
+        bf16_t* dqp = a.dq + ((int64_t)b * Tq + q_base) * a.lddq + h * DH + dq_d0 + (ln & 15);
         if (sl * QS + QS <= Tq) {
 #pragma unroll
           for (int n = 0; n < NT; ++n)
+            if (n < ntw) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dqp[r * a.lddq + 16 * n] = (bf16_t)(dqa[n][r] * a.qscale);
+              for (int r = 0; r < 4; ++r) dqp[r * a.lddq + 16 * n] = (bf16_t)(dqa[n][r] * a.qscale);
+            }
         } else {
 #pragma unroll
           for (int n = 0; n < NT; ++n)
+            if (n < ntw) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (q_base + r < Tq) dqp[r * a.lddq + 16 * n] = (bf16_t)(dqa[n][r] * a.qscale);
+              for (int r = 0; r < 4; ++r)
+                if (q_base + r < Tq) dqp[r * a.lddq + 16 * n] = (bf16_t)(dqa[n][r] * a.qscale);
+            }
         }
       } else {
-        float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (lane & 15);
+        float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (ln & 15);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
+          if (n < ntw) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) wsp[r * DH + 16 * n] = dqa[n][r];
+            for (int r = 0; r < 4; ++r) wsp[r * DH + 16 * n] = dqa[n][r];
+          }
       }
     };
 
@@ -316,21 +373,21 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
       if (sl + 1 < nslice) issue_slice(sl + 1);
       // keep words: this wave's [2 blk][32 q] table, written by the lanes that fetched them one slice ahead
       if constexpr (DROP) {
-        kw_s[lane] = kw_next;
+        if (NBLK == 2 || lane < 32) kw_s[lane] = kw_next;
         kw_next = load_kw(sl + 1, kb);
       }
       const char* qs = smem + L::QS0 + (sl & 1) * L::SLICE_B;
       const char* dos = smem + L::DO0 + (sl & 1) * L::SLICE_B;
-      const char* kim = smem + L::KIMG + (64 * w) * ROWB;
+      const char* kim = smem + L::KIMG + (KPW * w) * ROWB;
       // dQ of the previous slice runs as filler: its k-steps sit between the groups of vector work below (at sl == 0 it
       // multiplies whatever the buffer holds and the result is dropped)
       dq_begin(slq);
       if (sl == 4) stamp();
       // ---- per key column: S = Q.K^T, dP = dO.V^T, then P and dS in registers and dS^T into LDS for the next iteration's dQ
-      bf16x8 pf[2][2], dsf[2][2];
+      bf16x8 pf[NBLK][2], dsf[NBLK][2];
       char* dstw = smem + L::DST0 + (sl & 1) * L::DST_B;
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
+      for (int blk = 0; blk < NBLK; ++blk) {
         f32x16 s, dp;
 #pragma unroll
         for (int v = 0; v < 16; ++v) { s[v] = 0.f; dp[v] = 0.f; }
@@ -338,20 +395,22 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
           auto ro_of = [&](int ks) __attribute__((always_inline)) { return ((ks & 1) ? rrd1 : rrd0) + 64 * (ks >> 1); };
           const char* kimb = kim + 32 * blk * ROWB;
           // fragments two k-steps ahead: a step's two MFMAs (64 cycles) are shorter than an LDS round trip
-          bf16x8 aq[3], ad[3], kf[3];
+          // (one wave per SIMD: two steps ahead; two per SIMD: one step ahead, the partner covers the rest - 12 registers)
+          constexpr int FD = NW == 4 ? 3 : 2;
+          bf16x8 aq[FD], ad[FD], kf[FD];
           auto fetch = [&](int ks) __attribute__((always_inline)) {
             const int ro = ro_of(ks);
-            aq[ks % 3] = *reinterpret_cast<const bf16x8*>(qs + ro);
-            ad[ks % 3] = *reinterpret_cast<const bf16x8*>(dos + ro);
-            kf[ks % 3] = *reinterpret_cast<const bf16x8*>(kimb + ro);
+            aq[ks % FD] = *reinterpret_cast<const bf16x8*>(qs + ro);
+            ad[ks % FD] = *reinterpret_cast<const bf16x8*>(dos + ro);
+            kf[ks % FD] = *reinterpret_cast<const bf16x8*>(kimb + ro);
           };
-          fetch(0);
-          fetch(1);
+#pragma unroll
+          for (int ks = 0; ks < FD - 1; ++ks) fetch(ks);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 2 < KS) fetch(ks + 2);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks % 3], kf[ks % 3], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[ks % 3], vf[blk][ks], dp, 0, 0, 0);
+            if (ks + FD - 1 < KS) fetch(ks + FD - 1);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks % FD], kf[ks % FD], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[ks % FD], vf[blk][ks], dp, 0, 0, 0);
             FENCE();
           }
         }
@@ -363,7 +422,9 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sl * QS + 8 * j + 4 * g);
           u32x4 k4 = {0u, 0u, 0u, 0u};
           if constexpr (DROP) k4 = *reinterpret_cast<const u32x4*>(kw_s + 32 * blk + 8 * j + 4 * g);
-          dq_step(slq, 4 * blk + j);
+          // the KB / 32 k-steps of dQ, spread over the NBLK x 4 groups of vector work
+#pragma unroll
+          for (int u = 0; u < 2 / NBLK; ++u) dq_step(slq, (2 / NBLK) * (4 * blk + j) + u);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int v = 4 * j + r;
@@ -407,7 +468,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
             naqt = cat(lds_tr(qs + trs_lo + o2_of(i + 1)), lds_tr(qs + trs_hi + o2_of(i + 1)));
           }
 #pragma unroll
-          for (int blk = 0; blk < 2; ++blk) {
+          for (int blk = 0; blk < NBLK; ++blk) {
             dv[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adt, pf[blk][t], dv[blk][db], 0, 0, 0);
             dk[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqt, dsf[blk][t], dk[blk][db], 0, 0, 0);
           }
@@ -426,29 +487,39 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
     __syncthreads();
     stamp();
     if (false) __syncthreads();                                                    // every wave is done with the K image: it becomes the store staging area
-    // ---- dK, dV of this wave's 64 keys: registers -> [64][DH] bf16 tile in LDS -> whole rows to memory
+    // ---- dK, dV of this wave's keys: registers -> [KPW][DH] bf16 tile in LDS (padded rows) -> whole rows to memory
     {
-      char* st = smem + L::KIMG + w * (64 * ROWB);
+      constexpr int SRB = L::STG_ROWB;
+      char* st = smem + L::KIMG + w * (KPW * SRB);
+      int ln = lane;                                                      // opaque: see dq_load_partial
+      asm volatile("" : "+v"(ln));
+      const int lc = ln & 31, lgh = ln >> 5;
 #pragma unroll
       for (int which = 0; which < 2; ++which) {
         const float sc = which == 0 ? a.qscale : (DROP ? a.keep_scale : 1.f);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < NBLK; ++blk)
 #pragma unroll
           for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const f32x16& x = which == 0 ? dk[blk][db] : dv[blk][db];
               const bf16x4 o4 = {(bf16_t)(x[4 * j] * sc), (bf16_t)(x[4 * j + 1] * sc), (bf16_t)(x[4 * j + 2] * sc), (bf16_t)(x[4 * j + 3] * sc)};
-              *reinterpret_cast<bf16x4*>(st + (32 * blk + c) * ROWB + (32 * db + 8 * j + 4 * g) * 2) = o4;
+              *reinterpret_cast<bf16x4*>(st + (32 * blk + lc) * SRB + (32 * db + 8 * j + 4 * lgh) * 2) = o4;
             }
-        bf16_t* outp = which == 0 ? a.dk : a.dv;
         const int64_t ldo = which == 0 ? a.lddk : a.lddv;
+        bf16_t* outp = (which == 0 ? a.dk : a.dv) + ((int64_t)b * Tk + K0 + KPW * w) * ldo + h * DH;   // wave-uniform part
+        const int krem = Tk - (K0 + KPW * w);                             // rows of this wave's tile inside the tensor
+        bf16x8 val[KPW * CH / 64];
 #pragma unroll
-        for (int i = 0; i < 64 * CH / 64; ++i) {
-          const int n = lane + 64 * i, row = n / CH, ch = n % CH, key = K0 + 64 * w + row;
-          const bf16x8 val = *reinterpret_cast<const bf16x8*>(st + row * ROWB + ch * 16);
-          if (key < Tk) *reinterpret_cast<bf16x8*>(outp + ((int64_t)b * Tk + key) * ldo + h * DH + ch * 8) = val;
+        for (int i = 0; i < KPW * CH / 64; ++i) {
+          const int n = ln + 64 * i, row = n / CH, ch = n - row * CH;
+          val[i] = *reinterpret_cast<const bf16x8*>(st + row * SRB + ch * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < KPW * CH / 64; ++i) {
+          const int n = ln + 64 * i, row = n / CH, ch = n - row * CH;
+          if (row < krem) *reinterpret_cast<bf16x8*>(outp + (int64_t)row * ldo + ch * 8) = val[i];
         }
       }
     }
@@ -458,7 +529,7 @@ __global__ void __launch_bounds__(256) mha2_bwd_kernel(Args a) {
   {
     const bf16x8 zero = {};
     const int k_first = nkb * KB;
-    for (int n = tid; n < (Tk - k_first) * CH; n += 256) {
+    for (int n = tid; n < (Tk - k_first) * CH; n += NTHR) {
       const int key = k_first + n / CH, ch = n % CH;
       *reinterpret_cast<bf16x8*>(a.dk + ((int64_t)b * Tk + key) * a.lddk + h * DH + ch * 8) = zero;
       *reinterpret_cast<bf16x8*>(a.dv + ((int64_t)b * Tk + key) * a.lddv + h * DH + ch * 8) = zero;
@@ -731,6 +802,10 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
 }  // namespace a2
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+// waves of the fused backward's workgroup: 4 (default) or 8.  Measured at T = 500, dh = 96, B H = 256 (tools/exp/attn_driver): eight
+// waves 115 us without / 135 us with dropout against 118 / 118 us - every wave reads the whole Q / dO slice as its A operand, so
+// twice the waves double those LDS reads, and the dropout variant no longer fits 256 registers without spills in the slice loop
+static int g_opt_mha_bwd_waves = [] { const char* e = getenv("NEURST_MHA_BWD_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
 static int g_opt_fwd_ablate = 0;          // diagnostic: timing-only ablations of the wide forward (wrong results)
 extern int g_opt_mha_small_fused;         // attention.hip
 static int g_opt_mha_fused = [] { const char* e = getenv("NEURST_MHA_FUSED"); return e ? atoi(e) : 1; }();           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
@@ -738,6 +813,7 @@ int neurst_attention2_set_option(const char* name, int value) {
   if (!strcmp(name, "mha_fused")) { g_opt_mha_fused = value; return 1; }
   if (!strcmp(name, "mha_small_fused")) { g_opt_mha_small_fused = value; return 1; }
   if (!strcmp(name, "mha_fwd_ablate")) { g_opt_fwd_ablate = value; return 1; }
+  if (!strcmp(name, "mha_bwd_waves")) { if (value != 4 && value != 8) return 0; g_opt_mha_bwd_waves = value; return 1; }
   return 0;
 }
 
@@ -782,12 +858,15 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
   a.keep_scale = keep_scale(p.rate);
   const int tqp = (int)cdiv64(p.Tq, a2::QS) * a2::QS;
   const size_t smem = p.dh == 96 ? a2::Lds<96>::bytes(tqp) : a2::Lds<64>::bytes(tqp);
-  auto kern = a.stamps ? a2::mha2_bwd_kernel<96, true, true>
-                       : (p.rate > 0.f ? a2::mha2_bwd_kernel<96, true, false> : a2::mha2_bwd_kernel<96, false, false>);
-  if (p.dh == 64) kern = p.rate > 0.f ? a2::mha2_bwd_kernel<64, true, false> : a2::mha2_bwd_kernel<64, false, false>;
+  const bool w8 = g_opt_mha_bwd_waves == 8;
+  auto kern = a.stamps ? (w8 ? a2::mha2_bwd_kernel<96, true, true, 8> : a2::mha2_bwd_kernel<96, true, true, 4>)
+                       : (p.rate > 0.f ? (w8 ? a2::mha2_bwd_kernel<96, true, false, 8> : a2::mha2_bwd_kernel<96, true, false, 4>)
+                                       : (w8 ? a2::mha2_bwd_kernel<96, false, false, 8> : a2::mha2_bwd_kernel<96, false, false, 4>));
+  if (p.dh == 64) kern = p.rate > 0.f ? (w8 ? a2::mha2_bwd_kernel<64, true, false, 8> : a2::mha2_bwd_kernel<64, true, false, 4>)
+                                      : (w8 ? a2::mha2_bwd_kernel<64, false, false, 8> : a2::mha2_bwd_kernel<64, false, false, 4>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) { neurst_set_error("mha2_bwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
-  kern<<<dim3((unsigned)(p.B * p.H)), 256, smem, s>>>(a);
+  kern<<<dim3((unsigned)(p.B * p.H)), w8 ? 512 : 256, smem, s>>>(a);
   NEURST_CHECK_LAUNCH("mha2_bwd");
   return NEURST_OK;
 }

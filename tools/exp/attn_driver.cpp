@@ -22,8 +22,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&keep, kbb)); CK(hipMalloc(&ws, wsb ? wsb : 16));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (float rate : {0.0f, 0.1f}) {
-    for (int which = 0; which < 4; ++which) {
+    for (int which = 0; which < 5; ++which) {
       neurst_set_option("mha_fused", which >= 2 ? 2 : 0);
+      neurst_set_option("mha_bwd_waves", which == 4 ? 4 : 8);
       const int iters = 20;
       float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
@@ -38,8 +39,8 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
-      double fl = 4.0 * B * H * T * T * dh * ((which == 1 || which == 2) ? 2.5 : 1.0);
-      printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which == 3 ? "fwd(wide)  " : which == 2 ? "bwd(fused) " : which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
+      double fl = 4.0 * B * H * T * T * dh * ((which == 1 || which == 2 || which == 4) ? 2.5 : 1.0);
+      printf("T=%ld rate=%.1f %s %8.1f us  %6.1f TF/s\n", (long)T, rate, which == 4 ? "bwd(fused,4 waves)" : which == 3 ? "fwd(wide)  " : which == 2 ? "bwd(fused,8 waves)" : which ? "bwd(dq+dkv)" : "fwd        ", ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
     }
   }
   for (int abl : {0, 1, 2, 4, 8, 15}) {   // timing-only ablations of the wide forward
@@ -56,7 +57,8 @@ int main(int argc, char** argv) {
     printf("fwd(wide) ablate %2d: %8.1f us\n", abl, ms * 1e3 / 20);
   }
   neurst_set_option("mha_fwd_ablate", 0);
-  {   // phase stamps of workgroup 0 of the fused backward (cycles)
+  for (int waves : {4, 8}) {   // phase stamps of workgroup 0 of the fused backward (cycles)
+    neurst_set_option("mha_bwd_waves", waves);
     long long* st; CK(hipMalloc(&st, 64 * 8)); CK(hipMemset(st, 0, 64 * 8));
     neurst_debug_mha2_stamps(st);
     neurst_set_option("mha_fused", 2);
@@ -66,7 +68,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     long long hs[64]; CK(hipMemcpy(hs, st, sizeof(hs), hipMemcpyDeviceToHost));
     neurst_debug_mha2_stamps(nullptr);
-    printf("stamps (delta cycles):");
+    printf("stamps, %d waves (delta cycles):", waves);
     for (int i = 1; i < 64 && hs[i]; ++i) printf(" %lld", hs[i] - hs[i - 1]);
     printf("\n");
   }

@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 mode = sys.argv[2] if len(sys.argv) > 2 else 'summary'
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:70], r['Stream_Id'], int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])))
             for r in rows)
-adam = [i for i, e in enumerate(ev) if e[2].startswith('adam_kernel')]
+adam = [i for i, e in enumerate(ev) if 'adam_kernel' in e[2]]
 if mode == 'summary':
     a, b = adam[-4], adam[-1]
     d = collections.defaultdict(lambda: [0, 0])

@@ -13,7 +13,7 @@ def short(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])) for r in rows), key=lambda e: e[0])
 # steps are delimited by adam_kernel launches
-adam = [i for i, e in enumerate(ev) if e[2].startswith('adam_kernel')]
+adam = [i for i, e in enumerate(ev) if 'adam_kernel' in e[2]]
 assert len(adam) >= 4, 'need a few steps'
 a, b = adam[-4], adam[-1]                       # three whole steps
 seg = ev[a + 1:b + 1]
