@@ -243,7 +243,8 @@ gemm_kernel(GemmArgs g) {
   // at once, the gate one half ahead.  In the general passes below every such load is followed by s_waitcnt vmcnt(0),
   // which also waits for the previous pass's store: 16 dependent round trips to HBM per tile (the ffn2 data gradient
   // with its gate took 131 us in the step against 99 us on cache-resident operands).
-  if constexpr (sizeof(T) == 2 && SUMOP == 0) {
+  // (weight gradients too - fp32 C += - whose eight store passes each waited for the old C behind the previous pass's store)
+  if constexpr (sizeof(T) == 2) {
     const bool interior = g.split_k <= 1 && g.c_vec && wrow0 + 64 <= g.M && wcol0 + 64 <= g.N;
     if (__builtin_amdgcn_readfirstlane((int)interior)) {
       const int cc = (lane & 7) * 8;
