@@ -645,6 +645,7 @@ int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TI
 static bool use_gemm256() { return g_opt_gemm256 != 0; }
 int neurst_attention2_set_option(const char* name, int value);
 extern int g_opt_conv_fast;                                  // conv.hip
+extern int g_opt_ln_prefetch;                                // layernorm.hip
 extern "C" int neurst_set_option(const char* name, int value) {
   NEURST_CHECK_ARG(name, "set_option: null name");
   if (!strcmp(name, "gemm256")) g_opt_gemm256 = value;
@@ -652,6 +653,7 @@ extern "C" int neurst_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm256_bn")) g_opt_gemm256_bn = value;
   else if (!strcmp(name, "gemm256_ablate")) g_opt_gemm256_ablate = value;
   else if (!strcmp(name, "conv_fast")) g_opt_conv_fast = value;
+  else if (!strcmp(name, "ln_prefetch")) g_opt_ln_prefetch = value;
   else if (neurst_attention2_set_option(name, value)) {}
   else { neurst_set_error("set_option: unknown option '%s'", name); return NEURST_E_INVALID; }
   return NEURST_OK;

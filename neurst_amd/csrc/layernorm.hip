@@ -9,6 +9,9 @@
 
 template <typename T, int VEC> struct VecIO;
 template <> struct VecIO<float, 4> {
+  typedef f32x4 Raw;
+  static __device__ __forceinline__ Raw load_raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[4]) { v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
   static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
@@ -19,6 +22,12 @@ template <> struct VecIO<float, 4> {
   }
 };
 template <> struct VecIO<bf16_t, 8> {
+  typedef bf16x8 Raw;
+  static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+  }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -57,7 +66,7 @@ __device__ __forceinline__ bool ln_keep(uint32_t key, uint32_t inner0, bool idx3
 // ------------------------------------------------------------------ forward (vector path)
 // One wave owns R rows at a time (all their loads are issued before the first reduction, so R rows of
 // bytes are in flight per wave); a row lives in registers as NCH 16-byte chunks per lane.
-template <typename T, int VEC, int NCH, int R>
+template <typename T, int VEC, int NCH, int R, bool PF>
 __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __restrict__ yz, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
                                                    float* __restrict__ rstd, int64_t rows, int C, uint32_t thr, float scale,
@@ -74,8 +83,45 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __
     load_param<VEC>(beta, ch, ch < nchunks, pvec, bv[c]);
   }
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  // PF (one row per wave): the NEXT row's x and y are requested, as loaded (packed), before this row's stores go out.  The
+  // vector-memory counter is one in-order count of loads and stores: loads issued behind a row's stores cannot be waited
+  // for without waiting for those stores too, so every row used to cost a load AND a store round trip, one after the other.
+  typename VecIO<T, VEC>::Raw px[NCH], py[NCH];
+  if constexpr (PF) {
+    static_assert(R == 1, "the prefetching loop handles one row per wave");
+    const int64_t row = wave_id;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks && row < rows) {
+        px[c] = VecIO<T, VEC>::load_raw(x + row * C + (int64_t)ch * VEC);
+        py[c] = VecIO<T, VEC>::load_raw(yz + row * C + (int64_t)ch * VEC);
+      }
+    }
+  }
   for (int64_t row0 = wave_id * R; row0 < rows; row0 += nwaves * R) {
     float xv[R][NCH][VEC], z[R][NCH][VEC];
+    if constexpr (PF) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (lane + 64 * c < nchunks) {
+          VecIO<T, VEC>::unpack(px[c], xv[0][c]);
+          VecIO<T, VEC>::unpack(py[c], z[0][c]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { xv[0][c][j] = 0.f; z[0][c][j] = 0.f; }
+        }
+      }
+      const int64_t nrow = row0 + nwaves;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks && nrow < rows) {
+          px[c] = VecIO<T, VEC>::load_raw(x + nrow * C + (int64_t)ch * VEC);
+          py[c] = VecIO<T, VEC>::load_raw(yz + nrow * C + (int64_t)ch * VEC);
+        }
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -90,6 +136,7 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, T* __
           for (int j = 0; j < VEC; ++j) { xv[r][c][j] = 0.f; z[r][c][j] = 0.f; }
         }
       }
+    }
     float s[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -182,7 +229,7 @@ __global__ void ln_fwd_generic(const T* __restrict__ x, T* __restrict__ yz, cons
 // ------------------------------------------------------------------ backward (vector path)
 // DB: also dbias[col] += sum over rows of dy (the gradient of the bias of the dense layer that produced y: the weight-
 // gradient GEMM of that layer then needs no operand sum)
-template <typename T, int VEC, int NCH, bool DB>
+template <typename T, int VEC, int NCH, bool DB, bool PF>
 __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ gamma,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dz,
                                                    T* __restrict__ dy, float* __restrict__ partial, float* __restrict__ dgamma,
@@ -204,11 +251,28 @@ __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, c
     for (int j = 0; j < VEC; ++j) { dgam[c][j] = 0.f; dbet[c][j] = 0.f; if constexpr (DB) dbia[c][j] = 0.f; }
     load_param<VEC>(gamma, ch, ch < nchunks, pvec, gv[c]);
   }
-  for (int64_t row = (int64_t)blockIdx.x * nw + w; row < rows; row += (int64_t)gridDim.x * nw) {
+  // PF: the next row's dout and z are requested (packed, as loaded) before this row's stores go out - see ln_fwd_vec
+  typename VecIO<T, VEC>::Raw pd[NCH], pz[NCH];
+  const int64_t rstride = (int64_t)gridDim.x * nw;
+  if constexpr (PF) {
+    const int64_t row = (int64_t)blockIdx.x * nw + w;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks && row < rows) {
+        pd[c] = VecIO<T, VEC>::load_raw(dout + row * C + (int64_t)ch * VEC);
+        pz[c] = VecIO<T, VEC>::load_raw(z + row * C + (int64_t)ch * VEC);
+      }
+    }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * nw + w; row < rows; row += rstride) {
     bool keep_row = true;
     if (lens) keep_row = (row % Tn) < lens[row / Tn];
     const float mu = mean[row], rs = rstd[row];
-    float g[NCH][VEC], xh[NCH][VEC];
+    // PF keeps the row PACKED (as loaded) and converts it a second time for the output pass instead of holding g and x^
+    // in fp32: 2 x NCH x 4 registers instead of 2 x NCH x VEC (the 16-wave workgroup has 128 registers per lane)
+    float g[PF ? 1 : NCH][VEC], xh[PF ? 1 : NCH][VEC];
+    typename VecIO<T, VEC>::Raw cd[NCH], cz[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -216,21 +280,47 @@ __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, c
       if (ch < nchunks) {
         float dv[VEC], zv[VEC];
         int64_t off = row * C + (int64_t)ch * VEC;
-        VecIO<T, VEC>::load(dout + off, dv);
-        VecIO<T, VEC>::load(z + off, zv);
+        if constexpr (PF) {
+          cd[c] = pd[c];
+          cz[c] = pz[c];
+          VecIO<T, VEC>::unpack(cd[c], dv);
+          VecIO<T, VEC>::unpack(cz[c], zv);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float d = keep_row ? dv[j] : 0.f;
-          xh[c][j] = (zv[j] - mu) * rs;
-          dgam[c][j] += d * xh[c][j];
-          dbet[c][j] += d;
-          g[c][j] = d * gv[c][j];
-          s1 += g[c][j];
-          s2 += g[c][j] * xh[c][j];
+          for (int j = 0; j < VEC; ++j) {
+            const float d = keep_row ? dv[j] : 0.f, x = (zv[j] - mu) * rs, gg = d * gv[c][j];
+            dgam[c][j] += d * x;
+            dbet[c][j] += d;
+            s1 += gg;
+            s2 += gg * x;
+          }
+        } else {
+          VecIO<T, VEC>::load(dout + off, dv);
+          VecIO<T, VEC>::load(z + off, zv);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float d = keep_row ? dv[j] : 0.f;
+            xh[c][j] = (zv[j] - mu) * rs;
+            dgam[c][j] += d * xh[c][j];
+            dbet[c][j] += d;
+            g[c][j] = d * gv[c][j];
+            s1 += g[c][j];
+            s2 += g[c][j] * xh[c][j];
+          }
         }
-      } else {
+      } else if constexpr (!PF) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { g[c][j] = 0.f; xh[c][j] = 0.f; }
+      }
+    }
+    if constexpr (PF) {
+      const int64_t nrow = row + rstride;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks && nrow < rows) {
+          pd[c] = VecIO<T, VEC>::load_raw(dout + nrow * C + (int64_t)ch * VEC);
+          pz[c] = VecIO<T, VEC>::load_raw(z + nrow * C + (int64_t)ch * VEC);
+        }
       }
     }
     const float m1 = wave_sum_dpp(s1) * invC, m2 = wave_sum_dpp(s2) * invC;
@@ -240,8 +330,19 @@ __global__ void __launch_bounds__(1024) ln_bwd_vec(const T* __restrict__ dout, c
       if (ch < nchunks) {
         float o[VEC];
         int64_t off = row * C + (int64_t)ch * VEC;
+        if constexpr (PF) {
+          float dv[VEC], zv[VEC];
+          VecIO<T, VEC>::unpack(cd[c], dv);
+          VecIO<T, VEC>::unpack(cz[c], zv);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = rs * (g[c][j] - m1 - xh[c][j] * m2);
+          for (int j = 0; j < VEC; ++j) {
+            const float d = keep_row ? dv[j] : 0.f, x = (zv[j] - mu) * rs, gg = d * gv[c][j];
+            o[j] = rs * (gg - m1 - x * m2);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] = rs * (g[c][j] - m1 - xh[c][j] * m2);
+        }
         VecIO<T, VEC>::store(dz + off, o);
         if (thr) {
 #pragma unroll
@@ -333,6 +434,11 @@ __global__ void ln_bwd_generic(const T* __restrict__ dout, const T* __restrict__
 }
 
 // ------------------------------------------------------------------ host side
+// neurst_set_option("ln_prefetch", bits): 1 = forward, 2 = backward row loop with the next row requested ahead of the stores.
+// Measured on 16000 x 768 bf16, rate 0.1 (tools/bench_kernels.py ln, launch overhead included): forward 31.0 -> 29.6 us;
+// backward 33.6 -> 37.6 us - its 16-wave workgroups get 128 registers per lane and the 16 registers of the packed next row
+// push the column-sum accumulators into scratch inside the loop - so only the forward takes it by default.
+int g_opt_ln_prefetch = [] { const char* e = getenv("NEURST_LN_PREFETCH"); return e ? atoi(e) : 1; }();
 static inline int ln_nch(int64_t C, int vec) { return (int)cdiv64(C / vec, 64); }
 static inline bool ln_vec_ok(int64_t C, int vec, const void* a, const void* b, const void* c) {
   return C % vec == 0 && ln_nch(C, vec) <= 8 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0) && C % 4 == 0;
@@ -368,8 +474,12 @@ extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const f
   // persistent waves: at most 1024 workgroups, each wave walks rows with stride (measured best: 1 row in flight per wave)
   const int gv_ = (int)(g > 1024 ? 1024 : g);
 #define FWD_VEC(TT, VEC, NCH)                                                                                              \
-  ln_fwd_vec<TT, VEC, NCH, 1><<<gv_, 256, 0, s>>>((const TT*)x, (TT*)yz, gamma, beta, (TT*)out, mean, rstd, rows, (int)C, \
-                                                  thr, sc, key, inner0, idx32, lens, T)
+  if (g_opt_ln_prefetch & 1)                                                                                               \
+    ln_fwd_vec<TT, VEC, NCH, 1, true><<<gv_, 256, 0, s>>>((const TT*)x, (TT*)yz, gamma, beta, (TT*)out, mean, rstd, rows, (int)C, \
+                                                          thr, sc, key, inner0, idx32, lens, T);                           \
+  else                                                                                                                     \
+    ln_fwd_vec<TT, VEC, NCH, 1, false><<<gv_, 256, 0, s>>>((const TT*)x, (TT*)yz, gamma, beta, (TT*)out, mean, rstd, rows, (int)C, \
+                                                           thr, sc, key, inner0, idx32, lens, T)
 #define FWD_DISPATCH(TT, VEC)                                         \
   switch (ln_nch(C, VEC)) {                                           \
     case 1: FWD_VEC(TT, VEC, 1); break;                               \
@@ -413,12 +523,13 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
   const bool use_partial = partial != nullptr;
   const uint32_t inner0 = fmix32(key);
   const int idx32 = (double)rows * (double)C < 4294967296.0;
-#define BWD_VEC_DB(TT, VEC, NCH, DB)                                                                                         \
-  if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec<TT, VEC, NCH, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-  ln_bwd_vec<TT, VEC, NCH, DB><<<grid, nthr, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, use_partial ? partial : nullptr, \
-                                                        dgamma, dbeta, dbias, rows, (int)C, thr, sc, key, inner0, idx32, lens, T)
-#define BWD_VEC(TT, VEC, NCH) \
-  if (fuse_db) { BWD_VEC_DB(TT, VEC, NCH, true); } else { BWD_VEC_DB(TT, VEC, NCH, false); }
+#define BWD_VEC_DB(TT, VEC, NCH, DB, PF)                                                                                     \
+  if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec<TT, VEC, NCH, DB, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+  ln_bwd_vec<TT, VEC, NCH, DB, PF><<<grid, nthr, shmem, s>>>((const TT*)dout, (const TT*)z, gamma, mean, rstd, (TT*)dz, (TT*)dy, use_partial ? partial : nullptr, \
+                                                            dgamma, dbeta, dbias, rows, (int)C, thr, sc, key, inner0, idx32, lens, T)
+#define BWD_VEC(TT, VEC, NCH)                                                                                                \
+  if (g_opt_ln_prefetch & 2) { if (fuse_db) { BWD_VEC_DB(TT, VEC, NCH, true, true); } else { BWD_VEC_DB(TT, VEC, NCH, false, true); } } \
+  else { if (fuse_db) { BWD_VEC_DB(TT, VEC, NCH, true, false); } else { BWD_VEC_DB(TT, VEC, NCH, false, false); } }
 #define BWD_DISPATCH(TT, VEC)                                         \
   switch (ln_nch(C, VEC)) {                                           \
     case 1: BWD_VEC(TT, VEC, 1); break;                               \

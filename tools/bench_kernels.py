@@ -111,7 +111,10 @@ def bench_ln():
     y = torch.randn(rows, C, device=DEV).to(torch.bfloat16)
     g = torch.ones(C, device=DEV)
     b = torch.zeros(C, device=DEV)
-    for rate in (0.0, 0.1):
+    from neurst_amd import lib
+    for pf, rate in ((0, 0.0), (3, 0.0), (0, 0.1), (3, 0.1), (0, 0.1), (3, 0.1)):
+        lib.load().neurst_set_option(b'ln_prefetch', pf)
+        print('ln_prefetch', pf, end=': ')
         f = lambda: ops.dropout_add_layernorm_fwd(x, y, g, b, rate, 5)
         m, _ = timeit(f)
         print('ln fwd rate=%.1f %7.1f us  %6.0f GB/s (4*rows*C*2 B)' % (rate, m, 4 * rows * C * 2 / m / 1e3))
