@@ -133,12 +133,51 @@ class KernelTimer:
             return r
         ops.gemm_wgrad_grouped = gemm_wgrad_grouped
 
+    def wrap_others(self, ops):
+        """The other launch classes of the step, each with its ALGORITHMIC work: attention 4 / 10 B H Tq Tk dh flops
+        (forward / backward), LayerNorm 4 rows C elt bytes each way (3 in a backward without dropout), the CTC loss
+        B T V (4 + elt) bytes (fp32 logits in, gradient out), Adam 30 bytes per parameter (fp32 p, m, v read and written, g read,
+        bf16 shadow written).  A class is timed from the first to the last kernel of ONE host call."""
+        timer = self
+        self.bound = {}
+
+        def wrap(name, label, work, kind):
+            orig = getattr(ops, name)
+
+            def fn(*a, **kw):
+                if not timer.enabled:
+                    return orig(*a, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                st = ops.active_stream()
+                e0.record(st)
+                r = orig(*a, **kw)
+                e1.record(st)
+                lab = label(*a, **kw)
+                timer.records.setdefault(lab, []).append((e0, e1, float(work(*a, **kw))))
+                timer.bound[lab] = kind
+                return r
+            setattr(ops, name, fn)
+        es = lambda t: t.element_size()
+        wrap('mha_fwd', lambda q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, *a, **kw: 'attention forward (dh=%d, Tq=%d, Tk=%d)' % (dh, Tq, Tk),
+             lambda q, k, v, ldq, ldk, ldv, B, H, Tq, Tk, dh, *a, **kw: 4.0 * B * H * Tq * Tk * dh, 'mfma')
+        wrap('mha_bwd', lambda q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B, H, Tq, Tk, dh, *a, **kw:
+             'attention backward (dh=%d, Tq=%d, Tk=%d)' % (dh, Tq, Tk),
+             lambda q, k, v, o, d_o, lse, dq, dk, dv, ldq, ldk, ldv, lddq, lddk, lddv, B, H, Tq, Tk, dh, *a, **kw: 10.0 * B * H * Tq * Tk * dh, 'mfma')
+        wrap('dropout_add_layernorm_fwd', lambda x, *a, **kw: 'layernorm forward (%d rows)' % (x.numel() // x.shape[-1]),
+             lambda x, *a, **kw: 4.0 * x.numel() * es(x), 'hbm')
+        wrap('dropout_add_layernorm_bwd', lambda dout, z, gamma, mean, rstd, dgamma, dbeta, rate, *a, **kw: 'layernorm backward (%d rows)' % (dout.numel() // dout.shape[-1]),
+             lambda dout, z, gamma, mean, rstd, dgamma, dbeta, rate, *a, **kw: (4.0 if rate else 3.0) * dout.numel() * es(dout), 'hbm')
+        wrap('ctc_loss_fwd_bwd', lambda logits, *a, **kw: 'ctc loss + gradient (prep, frame, alpha-beta, fix)',
+             lambda logits, len_logits, labels, len_labels, grad_dtype, *a, **kw: logits.numel() * (4.0 + (2.0 if grad_dtype == ops.BF16 else 4.0)), 'hbm')
+        wrap('adam_step', lambda p, *a, **kw: 'adam', lambda p, g, m, v, shadow, *a, **kw: p.numel() * (28.0 + (2.0 if shadow is not None else 0.0)), 'hbm')
+
     def summary(self):
         out = {}
         for name, recs in self.records.items():
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             fl = [f for _, _, f in recs]
-            out[name] = {'launches': len(recs), 'total_ms': float(sum(ms)), 'avg_us': 1e3 * float(np.mean(ms)),
+            kind = getattr(self, 'bound', {}).get(name, 'mfma')
+            out[name] = {'launches': len(recs), 'total_ms': float(sum(ms)), 'avg_us': 1e3 * float(np.mean(ms)), 'bound': kind,
                          'flops_per_launch': float(np.mean(fl)), 'tflops': float(sum(fl) / (sum(ms) * 1e-3) / 1e12)}
         return out
 
@@ -203,8 +242,8 @@ def cpu_baseline(threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--raw-frames', type=int, default=1500)
     ap.add_argument('--config', default=os.path.join(ROOT, 'configs', 'lut.yaml'))
@@ -217,6 +256,10 @@ def main():
     ap.add_argument('--serial-streams', action='store_true',
                     help='no second HIP streams (CTC recursion, weight gradients): every kernel has the chip to itself, as in '
                          'the per-kernel timing pass; used for the rocprofv3 runs whose durations profiles/ holds')
+    ap.add_argument('--no-comm', action='store_true',
+                    help='N > 1: the step with the gradient all-reduce skipped (same streams, waits and bucket bookkeeping): the comm-off leg '
+                         'of the overlap report; the default run measures it as well, after the timed region, and reports both')
+    ap.add_argument('--bf16-buckets', action='store_true', help='N > 1: gradient buckets travel as bf16 (cast on the communication stream)')
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='debug: every rank uses cuda:0 and the gloo backend (exercises the N>1 code path on a 1-GPU box; not a measurement)')
     a = ap.parse_args()
@@ -251,6 +294,7 @@ def main():
     timer = KernelTimer()
     if not a.no_kernel_timing:
         timer.wrap_gemm(ops)
+        timer.wrap_others(ops)
 
     V, Ln = 10000, 40
     args = build_args(a.config, dim_output=V, compute_dtype=a.dtype)
@@ -262,6 +306,10 @@ def main():
     model = args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
     if a.serial_streams:
         model.graph.side_streams = False
+    if a.bf16_buckets:
+        model.bucketer.bf16 = True
+    if a.no_comm:
+        model.bucketer.skip_comm = True
     B, Traw = a.batch, a.raw_frames
     host = make_batch(B=B, Traw=Traw, V=V, L=Ln, U=40, Lb=40, bert_dim=768 if is_lut else None, seed=1234 + rank, ragged=a.ragged)
     batch = {k: torch.from_numpy(v).cuda() for k, v in host.items()}     # resident in HBM before the timed region
@@ -285,6 +333,28 @@ def main():
         tt = torch.tensor([dt], device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # N > 1: the same steps once more with the collective switched off (every rank, same streams and waits), outside the
+    # timed region: step time with and without the exchange shows how much of it backward hides
+    comm = None
+    if world > 1:
+        bk = model.bucketer
+        comm = {'buckets': len(bk.bounds), 'bucket_mb': [round((e - s) * 4 / 2 ** 20, 1) for s, e in bk.bounds], 'dtype': 'bf16' if bk.bf16 else 'f32',
+                'bytes_per_step_per_rank': int(bk.store.total * (2 if bk.bf16 else 4)), 'comm_on': not bk.skip_comm}
+        if not bk.skip_comm:
+            bk.skip_comm = True
+            for _ in range(2):
+                model.train_step_async(batch)
+            barrier()
+            t1 = time.perf_counter()
+            nn = max(a.steps // 2, 3)
+            for _ in range(nn):
+                model.train_step_async(batch)
+            barrier()
+            t_off = torch.tensor([(time.perf_counter() - t1) / nn], device='cuda')
+            dist.all_reduce(t_off, op=dist.ReduceOp.MAX)
+            comm['ms_per_step_comm_off'] = 1e3 * float(t_off.item())
+            comm['ms_per_step_comm_on'] = 1e3 * dt / a.steps
+            bk.skip_comm = False
     # per-kernel pass, OUTSIDE the timed region (an event pair around every GEMM launch costs ~1.4 ms per step):
     # live HIP-event durations of the dominant kernel on the stream it is launched on.  The second streams are off in
     # this pass: in the timed region above weight gradients and the CTC recursion share the chip with the main
@@ -318,15 +388,24 @@ def main():
         roof = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': peak, 'traffic': None,
                 'step_algorithmic_tflop': tot / 1e12, 'step_achieved': tot / step_s / 1e12, 'step_frac': tot / step_s / 1e12 / peak}
         if kern:
+            # the dominant kernel over EVERY timed launch class (GEMM instantiations, attention, LayerNorm, CTC, Adam)
             dom = max(kern, key=lambda k: kern[k]['total_ms'])
             roof['traffic'], tinfo = pmc_traffic(dom, a.profile_tag)
             roof.update(tinfo)
             roof['kernel_timing'] = ('HIP events around each launch in %d extra steps with the second streams off (one kernel on the '
                                      'chip at a time; same mode as profiles/: bench.py --serial-streams under rocprofv3)' % ksteps)
-            roof.update(kernel=dom, achieved=kern[dom]['tflops'], frac=kern[dom]['tflops'] / peak,
-                        avg_launch_us=kern[dom]['avg_us'], flops_per_launch=kern[dom]['flops_per_launch'],
-                        gemm_ms_per_step={k: v['total_ms'] / ksteps for k, v in kern.items()},
-                        gemm_tflops={k: v['tflops'] for k, v in kern.items()})
+            if kern[dom]['bound'] == 'hbm':        # work is bytes: achieved in GB/s against the HBM peak
+                gbs = kern[dom]['tflops'] * 1e3
+                roof.update(bound='hbm', unit='GB/s', peak=PEAK_HBM_GBS, kernel=dom, achieved=gbs, frac=gbs / PEAK_HBM_GBS,
+                            avg_launch_us=kern[dom]['avg_us'], bytes_per_launch=kern[dom]['flops_per_launch'])
+            else:
+                roof.update(kernel=dom, achieved=kern[dom]['tflops'], frac=kern[dom]['tflops'] / peak,
+                            avg_launch_us=kern[dom]['avg_us'], flops_per_launch=kern[dom]['flops_per_launch'])
+            roof.update(gemm_ms_per_step={k: v['total_ms'] / ksteps for k, v in kern.items() if 'gemm' in k},
+                        gemm_tflops={k: v['tflops'] for k, v in kern.items() if 'gemm' in k},
+                        other_ms_per_step={k: v['total_ms'] / ksteps for k, v in kern.items() if 'gemm' not in k},
+                        other_achieved={k: ('%.0f GB/s' % (v['tflops'] * 1e3) if v['bound'] == 'hbm' else '%.0f TFLOP/s' % v['tflops'])
+                                        for k, v in kern.items() if 'gemm' not in k})
         else:
             roof.update(kernel='train step', achieved=roof['step_achieved'], frac=roof['step_frac'])
         res = {
@@ -341,6 +420,8 @@ def main():
                        'parallelism': 'dp%d' % world, 'loss': float(losses[0])},
             'roofline': roof,
         }
+        if comm is not None:
+            res['comm'] = comm
         if not a.no_cpu_baseline and world == 1:
             threads = min(os.cpu_count() or 1, 16)
             res['cpu_baseline'] = cpu_baseline(threads)

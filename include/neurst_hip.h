@@ -339,6 +339,22 @@ int neurst_sumsq_f32(const float* x, int64_t n, void* partial_f64, void* stream)
 int neurst_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int neurst_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 
+/* a19, the exchange itself, for hosts without torch.distributed: average_gradients of
+ * st/tools/tftools/gradientTools.py:7-37 (the towers' gradients summed per variable; the 1/N of the mean rides on
+ * neurst_adam_step's grad_scale) as in-place sums of buckets of the gradient arena over RCCL / xGMI, one process and one
+ * communicator per GPU.  RCCL is loaded at run time on the first call (NEURST_RCCL_LIB, else librccl.so.1 / librccl.so);
+ * NEURST_E_UNSUPPORTED when it cannot be.  Rank 0 calls neurst_comm_unique_id (neurst_comm_unique_id_bytes() = 128 bytes)
+ * and hands the bytes to the other ranks by its own means; every rank then calls neurst_comm_init with its device current.
+ * neurst_allreduce_bucket is asynchronous on `stream` (dtype NEURST_F32, or NEURST_BF16 for buckets cast with
+ * neurst_cast_f32_to_bf16); calls of all ranks must follow the same order.  The Python host of this repository
+ * (GradBucketer) drives the same collective through torch.distributed instead. */
+int neurst_comm_unique_id_bytes(void);
+int neurst_comm_unique_id(void* id_out);
+int neurst_comm_init(int rank, int world, const void* unique_id);
+int neurst_comm_world(void);
+int neurst_allreduce_bucket(void* ptr, int64_t count, int dtype, void* stream);
+int neurst_comm_destroy(void);
+
 /* a21 helper: greedy step bookkeeping of decoder_with_caching
  * (st/models/decoders/transformer_decoder.py:83-90): ids = argmax(logits[b,:]) (first max),
  * preds[b,step] = ids, finished |= ids==eos, len_decoded += 1-finished, n_unfinished += !finished. */

@@ -155,7 +155,7 @@ class TransformerTPE(Seq2SeqModel):
         if self.args.use_horovod:
             raise NotImplementedError('use_horovod: data parallelism is one process per GPU over RCCL (torch.distributed)')
         self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 64) * (1 << 20)) // 256 * 256, 256),
-                                     producer_streams=lambda: (self.graph.wgrad_stream, self._ctc_stream))
+                                     producer_streams=lambda: (self.graph.wgrad_stream, self._ctc_stream), cuts=self._bucket_cuts())
         self.graph.on_param_grad = self.bucketer.param_done
         self.graph.on_node_done = self.bucketer.node_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
@@ -163,6 +163,24 @@ class TransformerTPE(Seq2SeqModel):
         self.__class__.num_Instances += 1
         # [loss, shape_batch, op_optimize, debug] ordering of :193 as callables
         return [lambda: self.last.get('loss'), lambda: self.last.get('shape_batch'), self.train_step, lambda: None]
+
+    def _bucket_cuts(self):
+        """Arena offsets at which a gradient bucket must end (GradBucketer).  The arena is laid out in forward order and
+        backward completes it from the end - except the decoder's embedding table, first in the arena but complete as soon
+        as the decoder's backward is: it gets a bucket of its own.  Behind it sit the variables whose gradients complete
+        LAST (encoder_fc, the first acoustic block): the first `grad_tail_mb` (default 8) MB of them form the last bucket, so
+        that what is exchanged after backward has ended is a few MB and not a whole 64 MB bucket."""
+        tail = int(float(self.args.grad_tail_mb or 8) * (1 << 20)) // 4
+        pv = list(self.store.vars.values())                      # arena order
+        cuts, start = [], 0
+        if pv and pv[0].name.endswith('/embedding') and len(pv) > 1:
+            start = pv[1].offset
+            cuts.append(start)
+        for p in pv:
+            if p.offset >= start + tail:
+                cuts.append(p.offset)
+                break
+        return cuts
 
     def build_infer_graph(self):
         self._make_modules()

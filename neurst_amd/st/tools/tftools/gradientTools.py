@@ -15,12 +15,23 @@ import torch.distributed as dist
 _DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
 
 
+class _StreamDone:
+    """Handle of a bucket whose whole reduction (cast, collective, cast back) is already enqueued on the communication
+    stream: wait() = the current stream waits for that stream."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class _HostStagedWork:
     """Handle of a bucket that gloo reduces in pinned host memory: wait() = the host waits for the reduction, then the
     copy back to the device is enqueued on the communication stream and the current stream is made to wait for it."""
 
-    def __init__(self, work, host, dev, stream):
-        self.work, self.host, self.dev, self.stream = work, host, dev, stream
+    def __init__(self, work, host, dev, stream, widen=None):
+        self.work, self.host, self.dev, self.stream, self.widen = work, host, dev, stream, widen
 
     def wait(self):
         if self.work is not None:
@@ -28,6 +39,8 @@ class _HostStagedWork:
             self.work = None
             with torch.cuda.stream(self.stream):
                 self.dev.copy_(self.host, non_blocking=True)
+                if self.widen is not None:          # bf16 buckets: dev is the bf16 staging slice, widen() casts it back into the fp32 arena
+                    self.widen()
         torch.cuda.current_stream().wait_stream(self.stream)
 
 
@@ -43,7 +56,13 @@ class GradBucketer:
     completed while a node (one layer's backward closure) runs are updated when `node_done()` is called after it, by which
     time every kernel of that node - the data-gradient GEMM included - is in the stream the update waits for."""
 
-    def __init__(self, store, bucket_bytes=32 << 20, group=None, comm_stream=None, producer_streams=None):
+    def __init__(self, store, bucket_bytes=32 << 20, group=None, comm_stream=None, producer_streams=None, cuts=(), bf16=None):
+        """cuts: arena offsets (elements) at which a bucket must end - the model cuts the arena so that the gradients that
+        complete LAST (the first layers of the acoustic encoder, at the start of the arena) form a small bucket of their
+        own: what is reduced after backward has ended is then a few MB instead of a whole bucket.
+        bf16 (default: NEURST_BF16_BUCKETS=1): a bucket travels as bf16 - cast on the communication stream, summed by the
+        collective in bf16, widened back into the fp32 arena (Adam still accumulates in fp32): half the bytes per link,
+        at 2^-9 relative rounding per addend (tests state the tolerance)."""
         self.store = store
         self.producer_streams = producer_streams or (lambda: ())   # other streams that may hold gradient kernels
         self.group = group
@@ -62,21 +81,31 @@ class GradBucketer:
         # this mode has no overlap to measure - it is for checking the N > 1 arithmetic and call order on one GPU.
         self.host_stage = bool(self.reduce and self.use_stream and dist.get_backend(group) == 'gloo')
         self.host_buf = None
+        self.bf16 = bool(int(os.environ.get('NEURST_BF16_BUCKETS', '0'))) if bf16 is None else bool(bf16)
+        self.g16 = None                  # bf16 staging arena of the bf16 mode (allocated on first use)
+        # NEURST_NO_COMM=1 / bench.py --no-comm: everything a step does for the exchange - bucket bookkeeping, the
+        # communication stream's waits for the producer streams, the cast kernels of the bf16 mode - except the collective
+        # itself: the comm-off leg of the overlap report.  The gradients stay local sums.
+        self.skip_comm = bool(int(os.environ.get('NEURST_NO_COMM', '0')))
         self.apply_fn = None
         self.apply_in_backward = True    # False: buckets are only updated in finish(), in launch order, behind their all-reduce
         elems = max(bucket_bytes // 4, 1)
         # buckets follow arena order; a parameter belongs to the bucket of its first element
         self.bounds = []
+        edges = sorted({int(c) for c in cuts if 0 < int(c) < store.total} | {store.total})
         start = 0
-        while start < store.total:
-            end = min(start + elems, store.total)
-            self.bounds.append((start, end))
-            start = end
+        for edge in edges:
+            while start < edge:
+                end = min(start + elems, edge)
+                self.bounds.append((start, end))
+                start = end
         self.param_bucket = {}
         self.bucket_params = [0] * len(self.bounds)
+        starts = [b[0] for b in self.bounds]
+        import bisect
         for p in store.vars.values():
-            first = min(p.offset // elems, len(self.bounds) - 1)
-            last = min((p.offset + p.size - 1) // elems, len(self.bounds) - 1)
+            first = bisect.bisect_right(starts, p.offset) - 1
+            last = bisect.bisect_right(starts, p.offset + p.size - 1) - 1
             self.param_bucket[p.name] = (first, last)
             for b in range(first, last + 1):
                 self.bucket_params[b] += 1
@@ -143,21 +172,60 @@ class GradBucketer:
             print('[bucketer r%d] launch bucket %d of %d' % (dist.get_rank(), b, len(self.bounds)), flush=True)
         s, e = self.bounds[b]
         view = self.store.grads[s:e]
+        if self.bf16 and self.g16 is None:
+            self.g16 = torch.empty(self.store.total, dtype=torch.bfloat16, device=view.device)
+        wire = self.g16[s:e] if self.bf16 else view        # what the collective sees
+
+        def narrow():
+            if view.is_cuda:
+                from .... import ops
+                ops.cast_f32_to_bf16(view, wire)
+            else:
+                wire.copy_(view)                           # host tensors: test plumbing only
+
+        def widen():
+            if view.is_cuda:
+                from .... import ops
+                ops.cast_bf16_to_f32(wire, view)
+            else:
+                view.copy_(wire)
+
+        def collective(t):
+            if self.skip_comm:
+                return None
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.host_stage:
             if self.host_buf is None:
-                self.host_buf = torch.empty(self.store.total, dtype=self.store.grads.dtype).pin_memory()
+                self.host_buf = torch.empty(self.store.total, dtype=wire.dtype).pin_memory()
             self._wait_for_producers(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
-                self.host_buf[s:e].copy_(view, non_blocking=True)
+                if self.bf16:
+                    narrow()
+                self.host_buf[s:e].copy_(wire, non_blocking=True)
             self.comm_stream.synchronize()
-            self.handles[b] = _HostStagedWork(dist.all_reduce(self.host_buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True),
-                                              self.host_buf[s:e], view, self.comm_stream)
+            self.handles[b] = _HostStagedWork(collective(self.host_buf[s:e]), self.host_buf[s:e], wire, self.comm_stream,
+                                              widen if self.bf16 else None)
         elif self.comm_stream is not None:
             self._wait_for_producers(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
-                self.handles[b] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.bf16:
+                    narrow()
+                    h = collective(wire)
+                    if h is not None:
+                        h.wait()                           # RCCL work: makes the communication stream wait, not the host
+                    widen()
+                    self.handles[b] = _StreamDone(self.comm_stream)
+                else:
+                    self.handles[b] = collective(view)
         else:
-            self.handles[b] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.bf16:
+                narrow()
+                h = collective(wire)
+                if h is not None:
+                    h.wait()
+                widen()
+            else:
+                self.handles[b] = collective(view)
 
     def _apply(self, b):
         """Optimizer update of bucket b behind everything enqueued so far (current stream, producer streams, its all-reduce)."""

@@ -604,3 +604,7 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
         assert abs(d['value'] - 32 * 500 / (d['ms_per_step'] / 1e3)) < 1e-3 * d['value']
         assert ('COSTT' in d['config']['workload']) == ('costt.yaml' in cmd[-1])
         assert 0 < r['step_frac'] < 1 and 'traffic_stale' in r
+        # every launch class is timed, not only the GEMMs: the dominant kernel is chosen over the whole step
+        other = r['other_ms_per_step']
+        assert any('attention backward' in k for k in other) and any('layernorm' in k for k in other) and 'adam' in other
+        assert any('ctc loss' in k for k in other) and r['kernel'] in list(other) + list(r['gemm_ms_per_step'])

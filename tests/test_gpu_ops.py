@@ -331,6 +331,38 @@ def test_grouped_tile_queue_with_problems_the_tile_kernel_cannot_take(mode):
         assert relerr(host(s), rs) < 1e-5
 
 
+def test_comm_entry_points_over_rccl_one_rank():
+    """neurst_comm_* (a19 for hosts without torch.distributed): id -> init -> in-place all-reduce of an fp32 and a bf16
+    bucket on a side stream -> destroy, with one rank (the sum over one rank is the identity; more ranks need more GPUs:
+    RCCL refuses two ranks on one device), plus the argument checks."""
+    import ctypes
+    from neurst_amd import lib
+    C = lib.load()
+    assert C.neurst_comm_world() == 0
+    x = torch.arange(100000, dtype=torch.float32, device=DEV) * 0.5
+    assert C.neurst_allreduce_bucket(x.data_ptr(), x.numel(), 0, None) == -1 and b'no communicator' in C.neurst_last_error()
+    uid = ctypes.create_string_buffer(C.neurst_comm_unique_id_bytes())
+    assert C.neurst_comm_unique_id(uid) == 0, C.neurst_last_error()
+    assert C.neurst_comm_init(1, 1, uid) == -1                      # rank outside the world
+    assert C.neurst_comm_init(0, 1, uid) == 0, C.neurst_last_error()
+    try:
+        assert C.neurst_comm_world() == 1
+        assert C.neurst_comm_init(0, 1, uid) == -1 and b'already exists' in C.neurst_last_error()
+        st = torch.cuda.Stream()
+        h = x.to(torch.bfloat16)
+        want, want_h = x.clone(), h.clone()
+        st.wait_stream(torch.cuda.current_stream())
+        assert C.neurst_allreduce_bucket(x.data_ptr(), x.numel(), 0, st.cuda_stream) == 0, C.neurst_last_error()
+        assert C.neurst_allreduce_bucket(h.data_ptr(), h.numel(), 1, st.cuda_stream) == 0, C.neurst_last_error()
+        assert C.neurst_allreduce_bucket(x.data_ptr(), 0, 0, st.cuda_stream) == 0
+        assert C.neurst_allreduce_bucket(x.data_ptr(), 8, 7, st.cuda_stream) == -1
+        st.synchronize()
+        assert torch.equal(x, want) and torch.equal(h, want_h)
+    finally:
+        assert C.neurst_comm_destroy() == 0
+    assert C.neurst_comm_world() == 0 and C.neurst_comm_destroy() == 0
+
+
 def test_set_option_rejects_unknown_names():
     from neurst_amd import lib
     C = lib.load()

@@ -188,6 +188,78 @@ print('rank', rank, 'ok')
 '''
 
 
+WORKER2 = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+rank = int(sys.argv[1])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% sys.argv[2], rank=rank, world_size=2)
+from neurst_amd.st.tools.tftools.gradientTools import GradBucketer, average_gradients
+
+class P:
+    def __init__(s, name, off, size): s.name, s.offset, s.size = name, off, size
+class Store:
+    pass
+# arena in forward order: an "embedding" (complete mid-backward), the acoustic encoder's head (complete LAST), then the rest
+names = ['embedding', 'encoder_fc', 'enc0_qkv', 'enc0_ffn', 'enc1', 'ctc_head', 'enc2', 'dec', 'dec_fc']
+sizes = [4096, 256, 1024, 3072, 4096, 2048, 4096, 6144, 2048]
+offs = np.cumsum([0] + [-(-s // 64) * 64 for s in sizes])
+st = Store()
+st.vars = {n: P(n, int(offs[i]), sizes[i]) for i, n in enumerate(names)}
+st.total = int(offs[-1])
+emb_end, tail_end = int(offs[1]), int(offs[3])          # cuts: behind the embedding; behind the first 1280 "last" elements
+st.grads = torch.zeros(st.total)
+b = GradBucketer(st, bucket_bytes=4 * 4096, cuts=[emb_end, tail_end])
+assert (0, emb_end) in b.bounds and (emb_end, tail_end) in b.bounds, b.bounds          # both are buckets of their own
+assert all(e - s <= 4096 for s, e in b.bounds) and b.bounds[-1][1] == st.total and all(b.bounds[i][1] == b.bounds[i + 1][0] for i in range(len(b.bounds) - 1))
+tail = b.bounds.index((emb_end, tail_end))
+backward = ['dec_fc', 'dec', 'embedding', 'enc2', 'ctc_head', 'enc1', 'enc0_ffn', 'enc0_qkv', 'encoder_fc']
+base = torch.arange(st.total, dtype=torch.float32) / 64.0
+st.grads = base * (rank + 1)
+for n in backward:
+    b.param_done(st.vars[n])
+assert all(b.launched), b.launched                      # every bucket went out during "backward"
+assert b.order[-1] == tail, (b.order, tail)             # ... the small head bucket LAST: it is all that is exposed behind backward
+assert b.order.index(0) < b.order.index(tail) - 2       # the embedding's bucket left as soon as the decoder was done
+assert (b.bounds[tail][1] - b.bounds[tail][0]) * 4 <= 8 * 1024
+assert average_gradients(b) == 0.5 and torch.equal(st.grads, base * 3)
+# bf16 buckets: same call order; every addend is rounded to bf16 (2^-9 relative) and so is the collective's sum: stated
+# tolerance 2^-7 of the sum (three roundings of at most 2^-9 each) - against a 2^-24 fp32 exchange
+b16 = GradBucketer(st, bucket_bytes=4 * 4096, cuts=[emb_end, tail_end], bf16=True)
+st.grads = base * (rank + 1)
+for n in backward:
+    b16.param_done(st.vars[n])
+assert b16.order == b.order or sorted(b16.order) == sorted(range(len(b16.bounds)))
+average_gradients(b16)
+err = (st.grads - base * 3).abs()
+assert float(err.max()) > 0 and bool((err <= (base * 3).abs() * 2.0 ** -7 + 1e-30).all()), float(err.max())
+assert st.grads.dtype == torch.float32
+# comm off (bench.py --no-comm): the same bookkeeping and launch order, no collective - gradients stay the local sums
+bn = GradBucketer(st, bucket_bytes=4 * 4096, cuts=[emb_end, tail_end])
+bn.skip_comm = True
+st.grads = base * (rank + 1)
+for n in backward:
+    bn.param_done(st.vars[n])
+assert bn.order[-1] == tail and all(bn.launched)
+assert average_gradients(bn) == 0.5 and torch.equal(st.grads, base * (rank + 1))
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_grad_bucketer_cuts_bf16_buckets_and_comm_off_two_rank_gloo(tmp_path):
+    """Multi-GPU readiness of a19 (gradientTools.py:7-37) on two gloo ranks: the arena cut so that the gradients that
+    complete last form a small bucket that is launched last, the embedding's bucket leaves early; bf16 buckets with
+    their stated tolerance; the comm-off leg of the overlap report."""
+    script = tmp_path / 'worker2.py'
+    script.write_text(WORKER2 % ROOT)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 def test_grad_bucketer_two_rank_gloo(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % ROOT)
