@@ -304,3 +304,76 @@ def test_batch_past_32bit_indexing_gives_the_gradient_of_its_repeated_part():
     assert rel < 1e-2, rel
     del big, small, model
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: long utterances (configs_template/lut.yaml:101-107 - the last bucket boundary is 2050 frames after the
+# 3 x down-sampling; Traw = 6000 -> T = 2000).  The oracle would take minutes here: properties instead.
+
+def test_config5_long_utterance_step_is_finite_and_ctc_frames_sum_to_zero():
+    """LUT at the template's width and depth (4 + 4 + 4 blocks, bf16, dropout 0.1) on B = 8 utterances of 6000 raw frames
+    (T = 2000 encoder frames, ragged): every loss and every gradient finite, padded CTC frames contribute nothing; and the
+    CTC kernels alone at [4, 2000, 10000]: a gradient frame sums to zero, padding is exactly zero."""
+    model, _ = _lut_model()
+    Bl, Traw = 8, 6000
+    host = make_batch(B=Bl, Traw=Traw, V=V, L=40, U=40, Lb=40, bert_dim=768, seed=21, ragged=True)
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in host.items()}
+    out = model.forward_backward(batch)
+    torch.cuda.synchronize()
+    assert tuple(model.last['shape_batch'])[:2] == (Bl, 2000)
+    assert torch.isfinite(out).all() and float(out[0]) > 0
+    g = model.store.grads
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    loss2 = model.train_step(batch)[0]
+    assert np.isfinite(loss2)
+    del model, g
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(5)
+    Tl = 2000
+    logits = torch.randn(4, Tl, V, device=DEV) * 2.0
+    len_logits = torch.from_numpy(rng.integers(Tl // 2, Tl + 1, size=4).astype(np.int32)).to(DEV)
+    labels = torch.from_numpy(rng.integers(4, V - 1, size=(4, 40)).astype(np.int32)).to(DEV)
+    len_labels = torch.from_numpy(rng.integers(20, 41, size=4).astype(np.int32)).to(DEV)
+    loss, grad, _ = ops.ctc_loss_fwd_bwd(logits, len_logits, labels, len_labels, ops.F32, 1.0)
+    pad = torch.arange(Tl, device=DEV)[None, :] >= len_logits[:, None]
+    assert torch.isfinite(loss).all() and (loss > 0).all()
+    assert grad.sum(-1).abs().max().item() < 5e-4 and grad[pad].abs().max().item() == 0.0
+
+
+def test_attention_beyond_the_fused_kernels_query_limit_falls_back_to_the_tiled_pair():
+    """The one-kernel backward keeps the statistics of every query in LDS (MAX_TQ = 2048); longer inputs must take the tiled
+    dQ + dK/dV pair without being asked.  T = 2200 with every key at and behind 2000 masked and dO = 0 for the queries
+    behind 2000 is the SAME problem as T = 2000 on the truncated tensors, which the fused kernel takes: forward rows still
+    sum to one, and dQ / dK / dV of the first 2000 positions agree to bf16 rounding between the two paths; the keys
+    behind the length get exactly zero gradients."""
+    Bs, Tl, Ts = 2, 2200, 2000
+    g = torch.Generator(device='cpu').manual_seed(9)
+    qkv = (torch.randn(Bs, Tl, 3 * D, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    lens = torch.full((Bs,), Ts, dtype=torch.int32, device=DEV)
+    t = qkv.view(-1)
+    ones = qkv.clone()
+    ones[:, :, 2 * D:] = 1.0
+    to = ones.view(-1)
+    o1, lse1 = ops.mha_fwd(to, to[D:], to[2 * D:], 3 * D, 3 * D, 3 * D, Bs, H, Tl, Tl, DH, ops.MASK_KEYPAD, lens, 0.0, 3)
+    assert torch.isfinite(lse1).all() and (o1.float() - 1.0).abs().max().item() < 1e-2
+    o, lse = ops.mha_fwd(t, t[D:], t[2 * D:], 3 * D, 3 * D, 3 * D, Bs, H, Tl, Tl, DH, ops.MASK_KEYPAD, lens, 0.0, 3)
+    do = torch.randn(Bs, Tl, D, generator=g).to(DEV).to(torch.bfloat16)
+    do[:, Ts:] = 0
+    dqkv = torch.zeros_like(qkv)
+    dt = dqkv.view(-1)
+    ops.mha_bwd(t, t[D:], t[2 * D:], o, do, lse, dt, dt[D:], dt[2 * D:], 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, Bs, H, Tl, Tl, DH,
+                ops.MASK_KEYPAD, lens, 0.0, 3)
+    # the truncated problem (fused kernels: Tq = 2000 <= MAX_TQ)
+    qs = qkv[:, :Ts].contiguous()
+    ts_ = qs.view(-1)
+    o_s, lse_s = ops.mha_fwd(ts_, ts_[D:], ts_[2 * D:], 3 * D, 3 * D, 3 * D, Bs, H, Ts, Ts, DH, ops.MASK_KEYPAD, lens, 0.0, 3)
+    dqs = torch.zeros_like(qs)
+    dts = dqs.view(-1)
+    ops.mha_bwd(ts_, ts_[D:], ts_[2 * D:], o_s, do[:, :Ts].contiguous(), lse_s, dts, dts[D:], dts[2 * D:], 3 * D, 3 * D, 3 * D, 3 * D, 3 * D, 3 * D,
+                Bs, H, Ts, Ts, DH, ops.MASK_KEYPAD, lens, 0.0, 3)
+    torch.cuda.synchronize()
+    assert ((o[:, :Ts].float() - o_s.float()).abs().max() / o_s.float().abs().max()).item() < 2e-2
+    a, b = dqkv[:, :Ts].float(), dqs.float()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and b.abs().max().item() > 0
+    assert ((a - b).norm() / b.norm()).item() < 1e-2 and ((a - b).abs().max() / b.abs().max()).item() < 3e-2
+    assert (dqkv[:, Ts:, D:] == 0).all()                      # masked keys: exactly zero dK, dV
