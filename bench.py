@@ -256,6 +256,7 @@ def main():
     ap.add_argument('--serial-streams', action='store_true',
                     help='no second HIP streams (CTC recursion, weight gradients): every kernel has the chip to itself, as in '
                          'the per-kernel timing pass; used for the rocprofv3 runs whose durations profiles/ holds')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the COSTT (BASELINE config 3) figure that rides along in the LUT line')
     ap.add_argument('--no-comm', action='store_true',
                     help='N > 1: the step with the gradient all-reduce skipped (same streams, waits and bucket bookkeeping): the comm-off leg '
                          'of the overlap report; the default run measures it as well, after the timed region, and reports both')
@@ -371,6 +372,35 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
         model.graph.side_streams = side_streams
+    # BASELINE config 3 rides along (rank 0 of a one-GPU run of the default LUT config): the COSTT step - d = 512, 6 + 6 + 6
+    # blocks, shrink layer, SpecAugment, L = 80 - measured AFTER the LUT regions on the same GPU, same batch shape
+    secondary = None
+    if world == 1 and is_lut and not a.no_secondary and os.path.basename(a.config) == 'lut.yaml':
+        try:
+            cargs = build_args(os.path.join(ROOT, 'configs', 'costt.yaml'), dim_output=V, compute_dtype=a.dtype)
+            cmodel = cargs.Model(GlobalStep(1000), encoder=cargs.model.encoder.type, decoder=cargs.model.decoder.type, is_train=True, args=cargs)
+            chost = make_batch(B=B, Traw=Traw, V=V, L=80, U=40, Lb=40, bert_dim=None, seed=1234, ragged=a.ragged)
+            cbatch = {k: torch.from_numpy(v).cuda() for k, v in chost.items()}
+            for _ in range(3):
+                cmodel.train_step_async(cbatch)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            csteps = max(min(a.steps, 20), 2)
+            for _ in range(csteps):
+                cout = cmodel.train_step_async(cbatch)
+            torch.cuda.synchronize()
+            cdt = (time.perf_counter() - c0) / csteps
+            T2c = int(cmodel.last['encoded'].shape[1])
+            cfl = lut_step_flops(B, T, 80, 40, V, d=cargs.model.encoder.num_cell_units, nenc=cargs.model.encoder.num_blocks,
+                                 nenc2=cargs.model.encoder2.num_blocks, ndec=cargs.model.decoder.num_blocks, T2=T2c, kd=False)[1]
+            secondary = {'costt': {'workload': 'COSTT train step (configs/costt.yaml: shrink layer, SpecAugment), %d x %d raw frames (T=%d, %d after '
+                                               'the shrink layer), V=10000, L=80, dropout 0.1' % (B, Traw, T, T2c),
+                                   'ms_per_step': 1e3 * cdt, 'value': B * T / cdt, 'unit': 'encoder frames/s', 'steps': csteps,
+                                   'step_achieved_tflops': cfl / cdt / 1e12, 'loss': float(cout.cpu().numpy()[0]),
+                                   'note': 'host-bound: one read-back per step sizes the shrunk tensor (st/models/tools/blocks.py:8-38)'}}
+            del cmodel, cbatch
+        except Exception as e:      # the headline line must not depend on the secondary figure
+            secondary = {'costt': {'error': repr(e)}}
     if use_dist:
         dist.barrier()
     losses = out4.cpu().numpy()
@@ -422,6 +452,8 @@ def main():
         }
         if comm is not None:
             res['comm'] = comm
+        if secondary is not None:
+            res['secondary'] = secondary
         if not a.no_cpu_baseline and world == 1:
             threads = min(os.cpu_count() or 1, 16)
             res['cpu_baseline'] = cpu_baseline(threads)

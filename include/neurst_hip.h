@@ -275,6 +275,12 @@ int neurst_shrink_fwd(const void* x, const int32_t* index, void* out, int64_t B,
                       int64_t D, int dtype, void* stream);
 int neurst_shrink_bwd(const void* dout, const int32_t* index, void* dx, int64_t B, int64_t T, int64_t Tout,
                       int64_t D, int dtype, void* stream);
+/* a13 without the device -> host read that sizes the reference's output (st/models/tools/blocks.py:26-36: zero-pad to the
+ * longest kept sequence): the host allocates Tout = `bound` rows per utterance from earlier steps' maxima; this call
+ * clamps new_len[b] to bound, writes state[1] = max_b new_len[b] (before clamping) and state[0] = 1 if that exceeded the
+ * bound, else 0.  Any bound >= the true maximum gives the reference's result on every valid position (padding rows are
+ * zero and masked by length); on overflow the caller discards the step (neurst_adam_step_guarded) and repeats it. */
+int neurst_shrink_clamp(int32_t* new_len, int64_t B, int bound, int32_t* state, void* stream);
 
 /* a17: smoothing_cross_entropy + mask + per-utterance mean, st/models/model_tools.py:17-38,
  * st/models/seq2seqModel.py:157-191.  logits [B,L,V] fp32; xent [B,L] fp32 (masked, divided
@@ -328,6 +334,12 @@ int neurst_maxpool3x3_bwd(const void* dout, const int8_t* argidx, void* dx, int6
  * shadow (may be NULL) receives the bf16 copy of the updated parameters. */
 int neurst_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
                      float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same update with a device-side veto (no reference counterpart): when skip_flag is not NULL and *skip_flag != 0 at
+ * execution time the launch changes nothing.  Used with neurst_shrink_clamp: a step whose shrunk tensor did not fit the
+ * length the host had guessed must not reach the parameters (the host repeats that batch). */
+int neurst_adam_step_guarded(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                             float lr_t, float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_flag,
+                             void* stream);
 /* handle_gradients (st/tools/tftools/gradientTools.py:40-67), the two rules that reach this model's variables (the value and
  * per-variable norm clips only touch variables named *lstm*): L2 penalty g += lambda * v on non-bias variables = axpy on
  * the variable's slice of the gradient arena; tf.clip_by_global_norm needs sqrt(sum g^2) over all gradients: block partials

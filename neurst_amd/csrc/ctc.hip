@@ -610,6 +610,36 @@ extern "C" int neurst_shrink_bwd(const void* dout, const int32_t* index, void* d
   return NEURST_OK;
 }
 
+// Speculative sizing of the shrunk tensor (no reference counterpart: st/models/tools/blocks.py:8-38 sizes it by a
+// device -> host read of the counts, which stalls the host until the acoustic encoder has run): the host allocates for a
+// bound it guesses from earlier steps; this kernel clamps the counts to the bound (every later kernel reads lengths from
+// the device), reports the true maximum and raises a flag when a count did not fit - the guarded Adam entry point then
+// leaves the parameters alone and the host repeats the batch with the full length.  state[0] = overflow, state[1] = max.
+__global__ void __launch_bounds__(256) shrink_clamp_kernel(int32_t* __restrict__ len, int64_t B, int bound, int32_t* __restrict__ state) {
+  __shared__ int red[4];
+  int m = 0;
+  for (int64_t i = threadIdx.x; i < B; i += 256) {
+    const int v = len[i];
+    m = v > m ? v : m;
+    if (v > bound) len[i] = bound;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int mm = red[0];
+    for (int w = 1; w < 4; ++w) mm = red[w] > mm ? red[w] : mm;
+    state[1] = mm;
+    state[0] = mm > bound ? 1 : 0;
+  }
+}
+extern "C" int neurst_shrink_clamp(int32_t* new_len, int64_t B, int bound, int32_t* state, void* stream) {
+  NEURST_CHECK_ARG(new_len && state && B > 0 && bound > 0, "shrink_clamp: bad arguments");
+  shrink_clamp_kernel<<<1, 256, 0, as_stream(stream)>>>(new_len, B, bound, state);
+  NEURST_CHECK_LAUNCH("shrink_clamp");
+  return NEURST_OK;
+}
+
 // ---------------------------------------------------------------- a17 label-smoothed cross entropy
 template <typename TG>
 __global__ void __launch_bounds__(256) ls_xent_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,

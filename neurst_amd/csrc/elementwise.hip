@@ -298,7 +298,9 @@ extern "C" int neurst_embedding_bwd(const int32_t* ids, const void* dout, float*
 // per step and is larger than the Infinity Cache, so keeping its lines helps nobody
 template <int EPT, bool NTEMP>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            bf16_t* __restrict__ shadow, int64_t n, float lr_t, float b1, float b2, float eps, float gs) {
+                            bf16_t* __restrict__ shadow, int64_t n, float lr_t, float b1, float b2, float eps, float gs,
+                            const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;     // guarded update (neurst_adam_step_guarded): a device-side veto, the same for every workgroup
   const int64_t n4 = n >> 2;
   auto ld = [](const float* q, int64_t i) __attribute__((always_inline)) {
     const f32x4* a = reinterpret_cast<const f32x4*>(q) + i;
@@ -346,8 +348,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     if (shadow) shadow[i] = (bf16_t)pj;
   }
 }
+extern "C" int neurst_adam_step_guarded(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr_t,
+                                        float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_flag, void* stream);
 extern "C" int neurst_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr_t,
                                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  return neurst_adam_step_guarded(p, g, m, v, shadow_bf16, n, lr_t, beta1, beta2, eps, grad_scale, nullptr, stream);
+}
+extern "C" int neurst_adam_step_guarded(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr_t,
+                                        float beta1, float beta2, float eps, float grad_scale, const int32_t* skip_flag, void* stream) {
   NEURST_CHECK_ARG(n > 0, "adam_step: n <= 0");
   NEURST_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: arenas must be 16-byte aligned");
   NEURST_CHECK_ARG(((uintptr_t)shadow_bf16 & 7) == 0, "adam_step: shadow must be 8-byte aligned");
@@ -359,7 +367,7 @@ extern "C" int neurst_adam_step(float* p, const float* g, float* m, float* v, vo
   int64_t ablocks = cdiv64(n >> 2, 256 * ept);
   NEURST_CHECK_ARG(ablocks < (int64_t)1 << 31, "adam_step: n too large for one launch");
   if (ablocks < 1) ablocks = 1;
-#define ADAM(EPT, NTEMP) adam_kernel<EPT, NTEMP><<<(unsigned)ablocks, 256, 0, as_stream(stream)>>>(p, g, m, v, (bf16_t*)shadow_bf16, n, lr_t, beta1, beta2, eps, grad_scale)
+#define ADAM(EPT, NTEMP) adam_kernel<EPT, NTEMP><<<(unsigned)ablocks, 256, 0, as_stream(stream)>>>(p, g, m, v, (bf16_t*)shadow_bf16, n, lr_t, beta1, beta2, eps, grad_scale, skip_flag)
   if (variant == 0) ADAM(1, false);
   else ADAM(2, true);
 #undef ADAM

@@ -413,6 +413,11 @@ def shrink_index(argmax, lens, blank):
     return index, new_len
 
 
+def shrink_clamp_(new_len, bound, state):
+    """new_len[b] = min(new_len[b], bound) in place; state[0] = overflow flag, state[1] = max before clamping (int32, device)"""
+    _chk(_C.neurst_shrink_clamp(_p(new_len), new_len.numel(), int(bound), _p(state), _s()), 'shrink_clamp')
+
+
 def shrink_fwd(x, index, Tout):
     B, T, D = x.shape
     out = torch.empty((B, Tout, D), dtype=x.dtype, device=x.device)
@@ -500,8 +505,13 @@ def maxpool3x3_bwd(dout, arg):
 
 
 # ---- optimiser / casts / greedy step ---------------------------------------------------------------------
-def adam_step(p, g, m, v, shadow, lr_t, beta1, beta2, eps, grad_scale):
-    _chk(_C.neurst_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()), 'adam_step')
+def adam_step(p, g, m, v, shadow, lr_t, beta1, beta2, eps, grad_scale, skip_flag=None):
+    """skip_flag: int32 device tensor; the update is a no-op when its first element is non-zero at execution time"""
+    if skip_flag is None:
+        _chk(_C.neurst_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()), 'adam_step')
+    else:
+        _chk(_C.neurst_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _p(skip_flag), _s()),
+             'adam_step_guarded')
 
 
 def axpy_f32(y, x, alpha):

@@ -16,7 +16,7 @@ import torch
 from . import graph as G
 from .kd_layer import compute_kd_loss, extract_feat
 from .seq2seqModel import Seq2SeqModel
-from .tools.blocks import shrink_layer
+from .tools.blocks import ShrinkSpeculation, shrink_layer
 from ..tools.tftools.gradientTools import GradBucketer, average_gradients, handle_gradients
 from ..tools.tftools.tfAudioTools import apply_specaugmant
 from ..tools.tftools import tfRecord
@@ -156,6 +156,12 @@ class TransformerTPE(Seq2SeqModel):
             raise NotImplementedError('use_horovod: data parallelism is one process per GPU over RCCL (torch.distributed)')
         self.bucketer = GradBucketer(self.store, bucket_bytes=max(int(float(self.args.grad_bucket_mb or 64) * (1 << 20)) // 256 * 256, 256),
                                      producer_streams=lambda: (self.graph.wgrad_stream, self._ctc_stream), cuts=self._bucket_cuts())
+        # shrink_layer (COSTT) without its mid-step read-back: NEURST_SHRINK_SPEC=0 restores the reference's behaviour
+        self.graph.shrink_spec = None
+        # (not with the KD branch: its attention over the shrunk sequence carries no key mask, so the padding counts there)
+        if (self.args.model.shrink_layer and self.device.type == 'cuda' and self.args.model.loss_type != 'ctc_kd_ce'
+                and os.environ.get('NEURST_SHRINK_SPEC', '1') != '0'):
+            self.graph.shrink_spec = ShrinkSpeculation(self.device)
         self.graph.on_param_grad = self.bucketer.param_done
         self.graph.on_node_done = self.bucketer.node_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
@@ -386,7 +392,7 @@ class TransformerTPE(Seq2SeqModel):
         al = G.ALIGN      # a variable owns its padding too: the ranges Adam still sees start on 256-byte boundaries
         return [(p.offset, p.offset + -(-p.size // al) * al) for p in self.store.vars.values() if any(s in p.name for s in self.frozen)]
 
-    def _step(self, batch):
+    def _step(self, batch, _replay=False):
         """forward + backward + gradient mean + Adam.  NEURST_OVERLAP_ADAM selects where the Adam kernel runs:
         `off`  (default) one launch over the whole arena after the gradient mean;
         `tail` per bucket, after backward, in the order the all-reduces were launched and on the communication stream -
@@ -395,9 +401,12 @@ class TransformerTPE(Seq2SeqModel):
         Measured on one MI355X with the bucket path forced on over RCCL (one rank, so no real traffic to hide behind):
         off 16.65, backward 16.67, tail 16.99 ms/step - 18 small Adam launches cost more than one large one, so the
         overlapped modes stay opt-in until a multi-GPU measurement says otherwise."""
+        spec = self.graph.shrink_spec
+        if spec is not None and not _replay:
+            self._settle_shrink(wait=False)
         mode = os.environ.get('NEURST_OVERLAP_ADAM') or 'off'
         mode = {'0': 'off', '1': 'backward'}.get(mode, mode)
-        overlap = mode in ('tail', 'backward') and (not self.frozen) and self.graph.side_streams and self.device.type == 'cuda'
+        overlap = mode in ('tail', 'backward') and (not self.frozen) and self.graph.side_streams and self.device.type == 'cuda' and spec is None
         if self.args.lambda_l2 or self.args.grad_clip_global_norm:
             overlap = False           # the L2 penalty and the global-norm clip need the complete averaged gradient before Adam
         self.bucketer.apply_in_backward = mode == 'backward'
@@ -414,13 +423,52 @@ class TransformerTPE(Seq2SeqModel):
             self.finish_update(self.store)
             self.last['lr'] = lr
         else:
-            self.last['lr'] = self.apply_gradients(self.store, scale, skip=self.frozen_ranges())
+            self.last['lr'] = self.apply_gradients(self.store, scale, skip=self.frozen_ranges(), skip_flag=None if spec is None else spec.state)
+        if spec is not None:
+            ev, host, bound = spec.last
+            spec.pending.append((ev, host, bound, batch, self.global_step.value - 1))
         return out4
+
+    def _settle_shrink(self, wait):
+        """Look at the shrink results of the steps whose GPU work has finished (wait=True: of every enqueued step): feed the
+        observed maxima to the bound heuristic, and repeat - with the full length - every batch whose kept frames did not
+        fit its bound (its Adam update was vetoed on the device).  The host-side step counters are rolled back first (a
+        vetoed step never happened): directly after a step whose losses were read back (train_step, nothing else enqueued)
+        the repeat IS that step, bit for bit; in train_step_async the batch is simply processed a few steps late."""
+        spec = self.graph.shrink_spec
+        redo = []
+        while spec.pending:
+            ev, host, bound, batch, step = spec.pending[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                break
+            spec.pending.popleft()
+            overflow, seen = int(host[0]), int(host[1])
+            spec.free.append((ev, host))
+            spec.history.append(max(seen, 1))
+            if overflow:
+                redo.append((batch, step))
+        out = None
+        for batch, step in redo:
+            self.global_step.value -= 1
+            self.store.adam_t -= 1
+            spec.force_full = True
+            try:
+                out = self._step(batch, _replay=True)
+            finally:
+                spec.force_full = False
+            self.last['shrink_replays'] = self.last.get('shrink_replays', 0) + 1
+        return out
 
     def train_step(self, batch):
         """One `sess.run([model.list_run, loss_ast, loss_am, loss_bert])` (run_lut.py:365-368):
         returns (loss, shape_batch, loss_ast, loss_ctc, loss_bert) as Python floats (one 16-byte read back)."""
         vals = self._step(batch).cpu().numpy()
+        if self.graph.shrink_spec is not None:                  # the read-back above has waited for the GPU: settle now, exactly
+            again = self._settle_shrink(wait=True)
+            if again is not None:
+                vals = again.cpu().numpy()
         self.last['loss'] = float(vals[0])
         self.loss_ast, self.loss_am, self.loss_bert = float(vals[1]), float(vals[2]), float(vals[3])
         return self.last['loss'], self.last['shape_batch'], self.loss_ast, self.loss_am, self.loss_bert

@@ -41,7 +41,7 @@ class LSTM_Model(object):
             raise NotImplementedError('only optimizer: adam is on the hot path')
         return self
 
-    def optimizer_update_fn(self, store, grad_scale):
+    def optimizer_update_fn(self, store, grad_scale, skip_flag=None):
         """-> (lr, fn): fn(start, end) enqueues this step's Adam update of arena[start:end] on the current stream
         (used to update gradient buckets while backward is still running); finish_update() closes the step."""
         lr = self.lr_at(self.global_step.value)
@@ -51,18 +51,18 @@ class LSTM_Model(object):
 
         def fn(s, e):
             _ops.adam_step(store.params[s:e], store.grads[s:e], store.m[s:e], store.v[s:e],
-                           None if store.shadow is None else store.shadow[s:e], lr_t, b1, b2, self.ADAM_EPS, grad_scale)
+                           None if store.shadow is None else store.shadow[s:e], lr_t, b1, b2, self.ADAM_EPS, grad_scale, skip_flag=skip_flag)
         return lr, fn
 
     def finish_update(self, store):
         store.adam_t += 1
         self.global_step.value += 1
 
-    def apply_gradients(self, store, grad_scale, skip=()):
+    def apply_gradients(self, store, grad_scale, skip=(), skip_flag=None):
         """TF Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v update; theta -= lr_t*m/(sqrt(v)+eps); global_step += 1.
         `skip`: arena ranges (start, end) of variables that are not handed to the optimizer (frozen_scope,
         TransformerTPE.py:171-183): their values and Adam slots stay bit-identical."""
-        lr, fn = self.optimizer_update_fn(store, grad_scale)
+        lr, fn = self.optimizer_update_fn(store, grad_scale, skip_flag=skip_flag)
         start = 0
         for s, e in sorted(skip):
             if s > start:

@@ -451,6 +451,43 @@ def test_template_width_bf16_against_the_oracle():
           % (abs(out4[0] - ref['loss']) / abs(ref['loss']), worst, worst_l2, worst_cos))
 
 
+def test_costt_speculative_shrink_bound_matches_the_read_back_path(monkeypatch):
+    """shrink_layer sized from earlier steps' maxima (no mid-step device -> host read) against the reference's sizing (read
+    the longest kept sequence back, blocks.py:26-36), four fp32 train steps over batches of growing length: the same losses
+    (1e-5 relative) and parameters (well-conditioned entries, 1e-4).  The third batch keeps more frames than the bound
+    guessed from the first two, so its Adam update must have been vetoed on the device and the batch repeated at full
+    length exactly once - global_step and adam_t still count four steps."""
+    batches = [make_batch(B=3, Traw=Traw, V=11, L=6, U=3, dim_raw=4, ragged=True, seed=40 + i) for i, Traw in enumerate((24, 24, 400, 60))]
+    got = {}
+    for spec in ('0', '1'):
+        monkeypatch.setenv('NEURST_SHRINK_SPEC', spec)
+        args = ge.tiny_args(compute_dtype='fp32', **CASES['costt'])
+        model = make_model(args)
+        if spec == '1':
+            assert model.graph.shrink_spec is not None
+            model.graph.shrink_spec.quantum = 4          # tiny shapes: keep the guessed bound close to the observed maxima
+            model.graph.shrink_spec.slack = 1
+            P = got['0'][2]
+            model.store.load_params(P)
+        else:
+            assert model.graph.shrink_spec is None
+            P = perturb(model, seed=6)
+        losses, kept = [], []
+        for b in batches:
+            losses.append(model.train_step(b)[0])
+            kept.append(int(model.last['len_encoded'].max().item()))
+        torch.cuda.synchronize()
+        got[spec] = (losses, model.store.params.clone(), P, kept, model.global_step.value, model.store.adam_t, model.last.get('shrink_replays', 0))
+    l0, p0, _, k0, gs0, t0, _ = got['0']
+    l1, p1, _, k1, gs1, t1, replays = got['1']
+    assert k0 == k1 and k0[2] > 1.25 * max(k0[:2]) + 4, k0       # the third batch really outgrows the guessed bound
+    assert replays == 1, replays
+    assert (gs0, t0) == (gs1, t1) and t1 - 0 >= 4
+    assert np.allclose(l1, l0, rtol=1e-5), (l1, l0)
+    sel = p0.abs() > 1e-4 * p0.abs().max()
+    assert torch.allclose(p1[sel], p0[sel], rtol=1e-4, atol=1e-6)
+
+
 RCCL_WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)
@@ -652,3 +689,5 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
         other = r['other_ms_per_step']
         assert any('attention backward' in k for k in other) and any('layernorm' in k for k in other) and 'adam' in other
         assert any('ctc loss' in k for k in other) and r['kernel'] in list(other) + list(r['gemm_ms_per_step'])
+        if 'costt.yaml' not in cmd[-1]:               # BASELINE config 3 rides along in the LUT line
+            assert d['secondary']['costt']['ms_per_step'] > 0 and 'COSTT' in d['secondary']['costt']['workload']
