@@ -128,11 +128,6 @@ class TransformerTPE(Seq2SeqModel):
         self.device = torch.device(device or ('cuda:%d' % torch.cuda.current_device()))
         self.store = get_variable_store(args, name, self.device)
         self.graph = G.Graph(self.store, self.store.compute_dtype, seed=args.seed or 0)
-        if args.model.shrink_layer and G.side_wgrad_rows_from_env() is None:
-            # The read-back that sizes shrink_layer's output drains the launch queue in mid-step; the small layers that
-            # follow are bound by the host's launch rate (measured: 13.9 of 14.4 ms/step), where the second stream's
-            # extra host work only costs.  The large layers of the acoustic encoder's backward still gain from it.
-            self.graph.side_wgrad_rows = (8192, 1 << 40)
         self.embed_table_decoder = self.get_embedding(embed_table=None, size_input=args.dim_output, size_embedding=self.size_embedding)
         if args.dirs and args.dirs.src_vocab:
             raise NotImplementedError('a separate source vocabulary (dirs.src_vocab) is outside the hot path')
@@ -162,6 +157,17 @@ class TransformerTPE(Seq2SeqModel):
         if (self.args.model.shrink_layer and self.device.type == 'cuda' and self.args.model.loss_type != 'ctc_kd_ce'
                 and os.environ.get('NEURST_SHRINK_SPEC', '1') != '0'):
             self.graph.shrink_spec = ShrinkSpeculation(self.device)
+        if self.args.model.shrink_layer and self.graph.shrink_spec is None and G.side_wgrad_rows_from_env() is None:
+            # The read-back that sizes shrink_layer's output drains the launch queue in mid-step; the small layers that
+            # follow are then bound by the host's launch rate (measured: 13.9 of 14.4 ms/step), where the second stream's
+            # extra host work only costs.  The large layers of the acoustic encoder's backward still gain from it.
+            self.graph.side_wgrad_rows = (8192, 1 << 40)
+        elif self.graph.shrink_spec is not None and 'NEURST_GROUP_MIN_ROWS' not in os.environ:
+            # With the host running ahead, the decoder's and the semantic encoder's weight gradients (2560 and ~1024 rows, 66
+            # launches of 20-40 us that occupy 36-144 CUs each) go out as whole-K tiles of the grouped kernel on the second
+            # stream instead: 11.98 -> 10.36 ms/step from the second stream alone, 10.10 with the groups (LUT, whose decoder
+            # has 1280 rows, measured slower with them: 13.15 -> 13.71, and keeps the 8192-row threshold)
+            self.graph.group_min_rows = 1024
         self.graph.on_param_grad = self.bucketer.param_done
         self.graph.on_node_done = self.bucketer.node_done
         self.frozen = [s for s in str(self.args.frozen_scope).split(',') if s] if self.args.frozen_scope else []
