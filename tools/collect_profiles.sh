@@ -1,15 +1,15 @@
 #!/bin/bash
 # On the GPU box (through gpurun): the five rocprofv3 passes behind profiles/<tag>_*  (tools/make_profiles.py <tag> turns them
 # into the committed summaries).  Each pass is a run of its own - counters never share a run with --kernel-trace/--stats.
-#   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh r03'
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --serial-streams"
-scmd="python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --serial-streams"
+cmd="python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary --serial-streams"
+scmd="python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-secondary --serial-streams"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $scmd > $out/stats.log 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- $cmd > $out/fetch.log 2>&1 &&
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- $cmd > $out/write.log 2>&1 &&
