@@ -269,7 +269,7 @@ class TransformerTPE(Seq2SeqModel):
         side = None
         if want_ctc_grad and not a.model.shrink_layer and encoded_am.is_cuda and g.side_streams:
             if self._ctc_stream is None:
-                self._ctc_stream = torch.cuda.Stream(device=self.device)
+                self._ctc_stream = G.shared_stream('ctc', self.device)
             side = self._ctc_stream
         defer = side is not None and _DEFER_CTC and a.model.use_semantic_encoder
         if defer:
@@ -304,7 +304,7 @@ class TransformerTPE(Seq2SeqModel):
                 rs = None
                 if logits_am.is_cuda and g.side_streams:
                     if self._ctc_stream is None:
-                        self._ctc_stream = torch.cuda.Stream(device=self.device)
+                        self._ctc_stream = G.shared_stream('ctc', self.device)
                     rs = self._ctc_stream
                 loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],
                                                     len_labels=batch['len_aux_label'], grad_scale=ctc_scale, recursion_stream=rs)

@@ -209,6 +209,24 @@ class _Scope:
         return False
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_stream(kind, device=None):
+    """The process's side stream of one kind ('wgrad', 'ctc', 'comm') on `device`.  HIP gives a process a handful of hardware
+    queues and streams that share one serialise (Hardware queues): two models in one process (bench.py's LUT and
+    COSTT steps, run_lut's train and dev graphs) must not each bring their own set.  Models of one process run one after the
+    other on the same host thread, so sharing a stream only adds the stream order they had anyway."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (kind, dev.index)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class Graph:
     """One model's execution context (TF: default graph + variable scope + train/eval flag)."""
 
@@ -302,7 +320,7 @@ class Graph:
         if not self.side_streams or device.type != 'cuda' or rows < lo or rows > hi:
             return None
         if self.wgrad_stream is None:
-            self.wgrad_stream = torch.cuda.Stream(device=device)
+            self.wgrad_stream = shared_stream('wgrad', device)
         return self.wgrad_stream
 
     def run_ahead(self, launch, device):
@@ -310,7 +328,7 @@ class Graph:
         weight-gradient stream - idle during forward - behind everything enqueued so far, and returns (its result, an
         event the consumer's stream has to wait for).  The result is allocated from the main stream's pool as usual."""
         if self.wgrad_stream is None:
-            self.wgrad_stream = torch.cuda.Stream(device=device)
+            self.wgrad_stream = shared_stream('wgrad', device)
         side = self.wgrad_stream
         side.wait_stream(torch.cuda.current_stream())      # the block handed out may still be read by earlier main-stream kernels
         ops.set_stream(side)
@@ -345,7 +363,7 @@ class Graph:
         if not self.side_streams or self.store.grads.device.type != 'cuda':
             return False
         if self.wgrad_stream is None:
-            self.wgrad_stream = torch.cuda.Stream(device=self.store.grads.device)
+            self.wgrad_stream = shared_stream('wgrad', self.store.grads.device)
         side = self.early_stream
         if side is None:
             side = self.wgrad_stream

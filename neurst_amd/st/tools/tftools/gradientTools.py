@@ -12,6 +12,11 @@ import numpy as np
 
 import torch.distributed as dist
 
+
+def _shared_stream(kind, device):
+    from ...models.graph import shared_stream       # one side stream of each kind per process and device
+    return shared_stream(kind, device)
+
 _DEBUG = bool(os.environ.get('NEURST_DEBUG_BUCKETS'))
 
 
@@ -71,7 +76,7 @@ class GradBucketer:
         # box, whenever a process group exists and NEURST_FORCE_BUCKETS is set (an all-reduce over one rank is the identity)
         self.reduce = self.world > 1 or (bool(os.environ.get('NEURST_FORCE_BUCKETS')) and dist.is_available() and dist.is_initialized())
         self.use_stream = store.grads.is_cuda
-        self.comm_stream = comm_stream or (torch.cuda.Stream() if (self.use_stream and self.reduce) else None)
+        self.comm_stream = comm_stream or (_shared_stream('comm', store.grads.device) if (self.use_stream and self.reduce) else None)
         # gloo with device tensors (two ranks rehearsing on ONE GPU; RCCL refuses that): gloo's own CUDA path - a pinned
         # copy per call on pool streams, host threads that synchronise them - hangs on this ROCm stack as soon as a few
         # asynchronous device-tensor all-reduces are in flight, with no code of this package involved
@@ -122,7 +127,7 @@ class GradBucketer:
 
     def _side_stream(self):
         if self.use_stream and self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream()
+            self.comm_stream = _shared_stream('comm', self.store.grads.device)
         return self.comm_stream
 
     def param_done(self, p):
