@@ -41,6 +41,28 @@ template <> struct VecIO<bf16_t, 8> {
   }
 };
 
+// 8-byte lanes: a 768-wide bf16 row is 192 chunks of 4 = three full wave passes, where 16-byte lanes give 96 chunks = one and a
+// half passes (half the wave idles in the second) and cost a third more registers per lane for the same row
+template <> struct VecIO<bf16_t, 4> {
+  typedef bf16x4 Raw;
+  static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)t[j];
+  }
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)t[j];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x4*>(p) = t;
+  }
+};
+
 // row-invariant parameter chunk (VEC consecutive floats) with 16-byte loads when the pointer allows
 template <int VEC>
 __device__ __forceinline__ void load_param(const float* __restrict__ p, int ch, bool valid, bool vec_ok, float (&v)[VEC]) {
@@ -438,7 +460,12 @@ __global__ void ln_bwd_generic(const T* __restrict__ dout, const T* __restrict__
 // Measured on 16000 x 768 bf16, rate 0.1 (tools/bench_kernels.py ln, launch overhead included): forward 31.0 -> 29.6 us;
 // backward 33.6 -> 37.6 us - its 16-wave workgroups get 128 registers per lane and the 16 registers of the packed next row
 // push the column-sum accumulators into scratch inside the loop - so only the forward takes it by default.
-int g_opt_ln_prefetch = [] { const char* e = getenv("NEURST_LN_PREFETCH"); return e ? atoi(e) : 1; }();
+int g_opt_ln_prefetch = [] { const char* e = getenv("NEURST_LN_PREFETCH"); return e ? atoi(e) : 13; }();
+// bits 4 / 8 of the same option: forward / backward take 8-byte lanes when a bf16 row is whole wave passes of them but not of
+// 16-byte lanes (C = 768: 3 x 64 x 4 against 1.5 x 64 x 8)
+static inline bool ln_lanes8(int64_t C, int bit) {
+  return (g_opt_ln_prefetch & bit) && C % 256 == 0 && C % 512 != 0 && C / 256 <= 4;
+}
 static inline int ln_nch(int64_t C, int vec) { return (int)cdiv64(C / vec, 64); }
 static inline bool ln_vec_ok(int64_t C, int vec, const void* a, const void* b, const void* c) {
   return C % vec == 0 && ln_nch(C, vec) <= 8 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0) && C % 4 == 0;
@@ -489,7 +516,7 @@ extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const f
     default: FWD_VEC(TT, VEC, 8); break;                              \
   }
   if (dtype == NEURST_BF16) {
-    if (ln_vec_ok(C, 8, x, yz, out)) { FWD_DISPATCH(bf16_t, 8) }
+    if (ln_vec_ok(C, 8, x, yz, out)) { if (ln_lanes8(C, 4)) { FWD_DISPATCH(bf16_t, 4) } else { FWD_DISPATCH(bf16_t, 8) } }
     else ln_fwd_generic<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)yz, gamma, beta, (bf16_t*)out, mean, rstd, rows, (int)C, thr, sc, key, lens, T);
   } else {
     if (ln_vec_ok(C, 4, x, yz, out)) { FWD_DISPATCH(float, 4) }
@@ -539,7 +566,7 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
     default: BWD_VEC(TT, VEC, 8); break;                              \
   }
   if (dtype == NEURST_BF16) {
-    if (ln_vec_ok(C, 8, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 150 * 1024) { vec = true; BWD_DISPATCH(bf16_t, 8) }
+    if (ln_vec_ok(C, 8, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 150 * 1024) { vec = true; if (ln_lanes8(C, 8)) { BWD_DISPATCH(bf16_t, 4) } else { BWD_DISPATCH(bf16_t, 8) } }
     else ln_bwd_generic<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dout, (const bf16_t*)z, gamma, mean, rstd, (bf16_t*)dz, (bf16_t*)dy, dgamma, dbeta, rows, (int)C, thr, sc, key, lens, T);
   } else {
     if (ln_vec_ok(C, 4, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 150 * 1024) { vec = true; BWD_DISPATCH(float, 4) }

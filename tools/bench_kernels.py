@@ -112,7 +112,8 @@ def bench_ln():
     g = torch.ones(C, device=DEV)
     b = torch.zeros(C, device=DEV)
     from neurst_amd import lib
-    for pf, rate in ((0, 0.0), (3, 0.0), (0, 0.1), (3, 0.1), (0, 0.1), (3, 0.1)):
+    pfs = [int(v) for v in os.environ.get('LN_PF', '0,3').split(',')]
+    for pf, rate in [(p_, r_) for r_ in (0.0, 0.1, 0.1) for p_ in pfs]:
         lib.load().neurst_set_option(b'ln_prefetch', pf)
         print('ln_prefetch', pf, end=': ')
         f = lambda: ops.dropout_add_layernorm_fwd(x, y, g, b, rate, 5)
