@@ -644,6 +644,21 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
   const int trs_hi = (4 * g + qq + 8) * ROWB + 16 * ((2 * (G & 1) + (p4 >> 1)) ^ (g + 2)) + 8 * (p4 & 1);
   char* const ost = smem + L::OST0 + w * L::OST_B;
 
+  // Stored dropout decisions (keep_ready): the words of a block are requested one block AHEAD, before that block's LDS-DMA
+  // pieces are issued.  The vector-memory counter retires in order and hipcc does not count the DMA statements: a keep word
+  // loaded behind them (as it was, inside the tile loop) made its "vmcnt(0)" wait for the whole next K / V block as well.
+  uint32_t kwn[2] = {0u, 0u};
+  auto load_kw = [&](int grp_, int kb_) __attribute__((always_inline)) {
+    const int q_ = (grp_ * FW + w) * QS + c;
+    const bool ok = q_ < Tq;
+    const int64_t rg = (int64_t)bh * Tq + (ok ? q_ : 0);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int wi = kb_ * (KBF / 32) + 2 * pr + g;
+      kwn[pr] = (ok && wi < a.nw) ? a.keep[rg * a.nw + wi] : 0u;
+    }
+  };
+  if constexpr (DROP) { if (a.keep_ready) load_kw(0, 0); }
   issue_block(0, 0);
   int it = 0;                                                             // blocks consumed so far (buffer = it & 1)
   for (int grp = 0; grp < ngroup; ++grp) {
@@ -670,9 +685,15 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
     for (int kb = 0; kb < nkb; ++kb, ++it) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's pieces of block `it` have landed
       __syncthreads();                                                    // everyone's have, and everyone has left the other buffer
+      uint32_t kwc0 = kwn[0], kwc1 = kwn[1];                              // this block's stored keep words (landed: waited for above)
       {
         const int nkb_next = kb + 1 < nkb ? kb + 1 : 0;
-        if (kb + 1 < nkb || grp + 1 < ngroup) issue_block(nkb_next, (it + 1) & 1);
+        const bool more = kb + 1 < nkb || grp + 1 < ngroup;
+        if constexpr (DROP) {
+          asm volatile("" : "+v"(kwc0), "+v"(kwc1));                      // their use stays in front of the next loads and DMA pieces
+          if (a.keep_ready && more) load_kw(kb + 1 < nkb ? grp : grp + 1, nkb_next);
+        }
+        if (more) issue_block(nkb_next, (it + 1) & 1);
       }
       const char* kim = smem + L::K0 + (it & 1) * L::IMG_B;
       const char* vim = smem + L::V0 + (it & 1) * L::IMG_B;
@@ -704,7 +725,7 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
           const int wi = kb * (KBF / 32) + 2 * pr + g;
           uint32_t mine;
           if (a.keep_ready) {                                             // wave-uniform
-            mine = (q_ok && wi < a.nw) ? a.keep[row_g * a.nw + wi] : 0u;
+            mine = pr == 0 ? kwc0 : kwc1;
           } else {
             mine = attn_keep_word(a.key, a.inner0, a.idx32, (uint64_t)(row_g * a.nw + wi), a.t16);
             if (a.keep && q_ok && wi < a.nw) a.keep[row_g * a.nw + wi] = mine;

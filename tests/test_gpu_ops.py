@@ -468,7 +468,7 @@ def test_layernorm_lane_widths_and_prefetch_agree(C):
             dz, dy = ops.dropout_add_layernorm_bwd(dout, yz, gam, mean, rstd, dg, db, rate, key, lens, T)
             res[bits] = [host(t) for t in (out, yz, mean, rstd, dz, dy, dg, db)]
     finally:
-        ops.set_option('ln_prefetch', 13)
+        ops.set_option('ln_prefetch', 5)
     # another lane layout sums a row in another order, and hipcc contracts the two loop shapes into different fma chains:
     # statistics and column sums agree to fp32 rounding, bf16 outputs to one rounding step; the residual sum is exact
     for bits in (3, 12, 15):
