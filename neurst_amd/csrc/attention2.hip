@@ -778,21 +778,31 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
 #pragma unroll
               for (int v = 0; v < 16; ++v) oacc[db][v] *= alpha;
           }
+          // probabilities in pairs: one v_cvt_pk_bf16_f32 per pair, and the dropout decisions applied to the PACKED pair - the
+          // keep bits of a pair are neighbours in the word, so its mask is two bit-field extracts and one bit-field insert
+          // (per element the compiler made three instructions of the mask and a cvt + perm of the packing: 71 vector
+          // instructions per tile, now 40)
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+          u32x4 pk[2];
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const float p = (ABL & 1) ? __builtin_fmaf(s[v], sc, -m_new) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], sc, -m_new));
-            lsum += p;
+          for (int i = 0; i < 8; ++i) {
+            const float x0 = __builtin_fmaf(s[2 * i], sc, -m_new), x1 = __builtin_fmaf(s[2 * i + 1], sc, -m_new);
+            const float p0 = (ABL & 1) ? x0 : __builtin_amdgcn_exp2f(x0), p1 = (ABL & 1) ? x1 : __builtin_amdgcn_exp2f(x1);
+            lsum += p0;
+            lsum += p1;
+            const bf16x2 pp = {(bf16_t)p0, (bf16_t)p1};
+            uint32_t w2 = __builtin_bit_cast(uint32_t, pp);
             if constexpr (DROP) {
-              const int mk = __builtin_amdgcn_sbfe(wg, 8 * (v >> 2) + (v & 3), 1);
-              s[v] = __builtin_bit_cast(float, __builtin_bit_cast(int, p) & mk);
-            } else {
-              s[v] = p;
+              const int pos = 8 * (i >> 1) + 2 * (i & 1);               // bit of element 2 i (element 2 i + 1: the next one)
+              const uint32_t t1 = (uint32_t)__builtin_amdgcn_sbfe(wg, pos, 1), t2 = (uint32_t)__builtin_amdgcn_sbfe(wg, pos, 2);
+              w2 &= (t2 & 0xffff0000u) | (t1 & 0x0000ffffu);            // every bit of t2 above bit 0 is the second element's decision
             }
+            pk[i >> 2][i & 3] = w2;
           }
           l_run = __builtin_fmaf(l_run, alpha, lsum);
           bf16x8 pf[2];
-          pf[0] = pack8(s, 0);
-          pf[1] = pack8(s, 1);
+          pf[0] = __builtin_bit_cast(bf16x8, pk[0]);
+          pf[1] = __builtin_bit_cast(bf16x8, pk[1]);
           // ---- O^T += V^T.P^T
 #pragma unroll
           for (int i = 0; i < 2 * DB; ++i) {
