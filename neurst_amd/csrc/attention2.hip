@@ -795,7 +795,7 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
             if constexpr (DROP) {
               const int pos = 8 * (i >> 1) + 2 * (i & 1);               // bit of element 2 i (element 2 i + 1: the next one)
               const uint32_t t1 = (uint32_t)__builtin_amdgcn_sbfe(wg, pos, 1), t2 = (uint32_t)__builtin_amdgcn_sbfe(wg, pos, 2);
-              w2 &= (t2 & 0xffff0000u) | (t1 & 0x0000ffffu);            // every bit of t2 above bit 0 is the second element's decision
+              w2 &= __builtin_amdgcn_perm(t2, t1, 0x07060100u);          // low half from t1, high half from t2 (every bit of t2 above bit 0 is the second element's decision)
             }
             pk[i >> 2][i & 3] = w2;
           }
