@@ -271,7 +271,7 @@ class Graph:
         self.group_launch_tiles = int(os.environ.get('NEURST_GROUP_TILES', '256'))
         self.pending_wgrads = []
         self.pending_tiles = 0
-        self.pending_reads = set()
+        self.pending_reads = {}
 
     def variable_scope(self, name):
         return _Scope(self, name)
@@ -428,9 +428,12 @@ class Graph:
         # workgroup per CU), the last gradient of the launch possibly only in part - its other tiles lead the next launch
         self.pending_wgrads.append([a, b, w, bias if layout == 'out_in' else None, bias, 0, tiles])
         self.pending_tiles += tiles
+        pr = self.pending_reads                 # storage -> number of waiting gradients that read it (kept incrementally: the
+        for t in (a, b):                        # queue holds dozens of entries when decoder-size layers take part)
+            k = t.untyped_storage().data_ptr()
+            pr[k] = pr.get(k, 0) + 1
         while self.pending_tiles >= self.group_launch_tiles:
             self.launch_wgrad_tiles(self.group_launch_tiles)
-        self.pending_reads = {t.untyped_storage().data_ptr() for e in self.pending_wgrads for t in e[:2]}
         return True
 
     def launch_wgrad_tiles(self, budget):
@@ -450,6 +453,13 @@ class Graph:
             if e[5] == tiles:
                 self.pending_wgrads.pop(0)
                 done.append((w, bias))
+                for t in (a, b):
+                    k = t.untyped_storage().data_ptr()
+                    n = self.pending_reads.get(k, 0) - 1
+                    if n > 0:
+                        self.pending_reads[k] = n
+                    else:
+                        self.pending_reads.pop(k, None)
         if not probs:
             return
         K = probs[0][0].shape[0]
@@ -470,7 +480,7 @@ class Graph:
         """Launch everything that is pending."""
         while self.pending_wgrads:
             self.launch_wgrad_tiles(self.group_launch_tiles)
-        self.pending_reads = set()
+        self.pending_reads = {}
 
     def before_inplace_write(self, t):
         """Main-stream kernels are about to update `t` in place: if a side-stream kernel may still read that storage,
