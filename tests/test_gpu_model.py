@@ -691,3 +691,21 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_keys():
         assert any('ctc loss' in k for k in other) and r['kernel'] in list(other) + list(r['gemm_ms_per_step'])
         if 'costt.yaml' not in cmd[-1]:               # BASELINE config 3 rides along in the LUT line
             assert d['secondary']['costt']['ms_per_step'] > 0 and 'COSTT' in d['secondary']['costt']['workload']
+
+
+def test_two_models_in_one_process_share_their_side_streams():
+    """HIP gives a process a handful of hardware queues: a second model must not bring a second set of side streams
+    (graph.shared_stream; with one set per model bench.py's COSTT step behind the LUT step ran 15.6 instead of 9.3 ms)."""
+    from neurst_amd.st.models import graph as G
+    batch = make_batch(B=2, Traw=24, V=11, L=5, U=3, Lb=4, bert_dim=16, dim_raw=4, ragged=True)
+    models = []
+    for lt in ('ctc_kd_ce', 'ce_ctc'):
+        args = ge.tiny_args(loss_type=lt, compute_dtype='bf16')
+        m = make_model(args)
+        m.train_step(batch)
+        models.append(m)
+    a, b = models
+    assert a.graph.wgrad_stream is not None and a.graph.wgrad_stream is b.graph.wgrad_stream
+    assert a._ctc_stream is not None and a._ctc_stream is b._ctc_stream
+    assert G.shared_stream('wgrad', a.device) is a.graph.wgrad_stream
+    assert np.isfinite(a.train_step(batch)[0]) and np.isfinite(b.train_step(batch)[0])     # interleaved use of the shared streams

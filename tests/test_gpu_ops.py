@@ -560,6 +560,7 @@ FUSED_BWD_CASES = [
     (2, 2, 200, 530, 'keypad', 0.0),      # three key blocks, Tq != Tk, no dropout
     (1, 2, 160, 256, 'none', 0.1),        # exactly one full block
     (3, 2, 128, 700, 'keypad', 0.1),      # a length of zero among the batch (every key biased)
+    (5, 2, 96, 300, 'none', 0.1),         # ten (batch, head) pairs: the XCD-contiguous workgroup order with a remainder (10 = 8 + 2)
 ]
 
 
