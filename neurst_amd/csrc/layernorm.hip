@@ -463,8 +463,8 @@ __global__ void ln_bwd_generic(const T* __restrict__ dout, const T* __restrict__
 int g_opt_ln_prefetch = [] { const char* e = getenv("NEURST_LN_PREFETCH"); return e ? atoi(e) : 5; }();
 // bits 4 / 8 of the same option: forward / backward take 8-byte lanes when a bf16 row is whole wave passes of them but not of
 // 16-byte lanes (C = 768: 3 x 64 x 4 against 1.5 x 64 x 8).  Measured at 16000 x 768, rate 0.1: forward 28.4 -> 26.8 us alone and
-// 0.392 -> 0.373 ms per step; the backward 32.2 -> 30.9 us alone but, in the step (with the fused bias gradient: 124 registers),
-// 0.510 -> 0.537 ms - so the forward takes them by default (bits 1 + 4) and the backward does not.
+// 0.392 -> 0.373 ms per step; the backward 32.2 -> 30.9 us alone but 0.510 -> 0.537 ms inside the step (same box, alternating
+// runs) - so the forward takes them by default (bits 1 + 4) and the backward does not.
 static inline bool ln_lanes8(int64_t C, int bit) {
   return (g_opt_ln_prefetch & bit) && C % 256 == 0 && C % 512 != 0 && C / 256 <= 4;
 }
