@@ -48,7 +48,10 @@ constexpr int EPI_BYTES = 4 * 32 * EPI_LD * 4;               // 4 waves x 32 row
 // workgroup, three of them hide each other's load latency), 1 elsewhere (LDS already limits those to one or two)
 template <typename T, bool TA, bool TB_KCONTIG, bool FAST, int NS>
 constexpr int gemm_min_waves() { return (sizeof(T) == 2 && !TA && !TB_KCONTIG && FAST && NS == 2) ? 3 : 1; }
-template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST, int SUMOP = 0, int NS = 2>
+// EPI: what the interior store passes know at compile time.  0: gate and accumulation are run-time flags; 1: neither (the forward
+// call of a dense layer); 2: C += only; 3: ReLU gate only (the host picks by relu_src / accumulate).  Every run-time flag in the
+// unrolled passes costs the K = 768 problems of the step 2-5 % (measured: see DESIGN.md, round 3).
+template <typename T, typename TC, bool TA, bool TB_KCONTIG, bool FAST, int SUMOP = 0, int NS = 2, int EPI = 0>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(gemm_min_waves<T, TA, TB_KCONTIG, FAST, NS>())))
 gemm_kernel(GemmArgs g) {
   // TB_KCONTIG: B stored [N][K] (trans_b = 1); otherwise B stored [K][N].  TA: A stored [K][M].
@@ -250,7 +253,7 @@ gemm_kernel(GemmArgs g) {
       const int cc = (lane & 7) * 8;
       const int64_t base = (wrow0 + (lane >> 3)) * g.ldc + wcol0 + cc;     // + (half * 32 + pass * 8) * ldc
       const bf16_t* const rsb = reinterpret_cast<const bf16_t*>(rs);
-      const bool gate = rsb != nullptr, accum = g.accumulate != 0;
+      const bool gate = EPI == 0 ? rsb != nullptr : EPI == 3, accum = EPI == 0 ? g.accumulate != 0 : EPI == 2;
       bf16x8 pg[2][4];
       f32x4 po[4][sizeof(TC) == 2 ? 1 : 2];
       auto fetch_gate = [&](int half) __attribute__((always_inline)) {
@@ -415,7 +418,7 @@ gemm_kernel(GemmArgs g) {
 // the hardware dispatcher + remap do for the plain kernel - and the tiles of the last partial round are dealt evenly to
 // the XCDs.  (Fetching tiles from per-XCD atomic counters instead cost 12-23 us per launch in contended atomics.)
 // bf16 operands, direct-to-LDS staging, whole K-tiles only (K % BK == 0, K / BK >= 3), split_k == 1
-template <typename TC, bool TA, bool TB_KCONTIG>
+template <typename TC, bool TA, bool TB_KCONTIG, bool SIMPLE>
 __global__ void __launch_bounds__(NT) gemm_persist_kernel(GemmArgs g) {
   typedef bf16_t T;
   constexpr int BK = (!TA && !TB_KCONTIG) ? 32 : GemmCfg<T>::BK;
@@ -495,7 +498,7 @@ __global__ void __launch_bounds__(NT) gemm_persist_kernel(GemmArgs g) {
       mma_tile<T, SA, SB, 0>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
       cur ^= 1;
     }
-    persist_epilogue<T, TC>(g, acc, bcol, Cs, m0 + wm * 64, n0 + wn * 64, lane);
+    persist_epilogue<T, TC, 4, SIMPLE>(g, acc, bcol, Cs, m0 + wm * 64, n0 + wn * 64, lane);
     tile = next; m0 = nm0; n0 = nn0;
     ++round;
   }
@@ -506,7 +509,7 @@ __global__ void __launch_bounds__(NT) gemm_persist_kernel(GemmArgs g) {
 // issues 64 MFMAs per K-step, so the K loop (12 - 156 steps) is a serial chain of ~0.45 us links.  32 x 128 tiles (wave
 // tile 16 x 64) put 240 workgroups on the chip with 16 MFMAs per wave and K-step.  Same 4-stage direct-to-LDS pipeline
 // as the small-grid path of gemm_kernel; A is K-contiguous (NT / NN).
-template <typename TC, bool TB_KCONTIG>
+template <typename TC, bool TB_KCONTIG, bool SIMPLE>
 __global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
   typedef bf16_t T;
   constexpr int BK = 64, NS = 4, BMT = 32;
@@ -575,7 +578,7 @@ __global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
     __syncthreads();
     mma_tile<T, SA, SB, 0, 1>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
   }
-  persist_epilogue<T, TC, 1>(g, acc, bcol, Cs, m0 + wm * 16, n0 + wn * 64, lane);
+  persist_epilogue<T, TC, 1, SIMPLE>(g, acc, bcol, Cs, m0 + wm * 16, n0 + wn * 64, lane);
 }
 
 static int thin_max_tiles() {
@@ -590,8 +593,9 @@ static bool launch_gemm_thin(const GemmArgs& g, int trans_a, int trans_b, hipStr
   GemmArgs t = g;
   t.tiles_m = (int)cdiv64(g.M, 32);
   const int grid = t.tiles_m * t.tiles_n;
-  if (trans_b) gemm_thin_kernel<TC, true><<<grid, NT, 0, s>>>(t);
-  else gemm_thin_kernel<TC, false><<<grid, NT, 0, s>>>(t);
+  const bool simple = !g.relu_src && !g.accumulate && g.c_vec && g.N % 8 == 0;
+  if (trans_b) { if (simple) gemm_thin_kernel<TC, true, true><<<grid, NT, 0, s>>>(t); else gemm_thin_kernel<TC, true, false><<<grid, NT, 0, s>>>(t); }
+  else { if (simple) gemm_thin_kernel<TC, false, true><<<grid, NT, 0, s>>>(t); else gemm_thin_kernel<TC, false, false><<<grid, NT, 0, s>>>(t); }
   return true;
 }
 
@@ -609,7 +613,8 @@ static bool launch_gemm_persist(const GemmArgs& g, int trans_a, int trans_b, hip
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
   if (g.split_k != 1 || g.K % 64 != 0 || g.K / 64 < 3 || tiles < persist_min_tiles()) return false;
   const int grid = 512;   // 2 resident workgroups on each of the 256 CUs; the kernel needs a multiple of 8
-  gemm_persist_kernel<TC, false, true><<<grid, NT, 0, s>>>(g);
+  if (!g.relu_src && !g.accumulate && g.c_vec && g.N % 8 == 0) gemm_persist_kernel<TC, false, true, true><<<grid, NT, 0, s>>>(g);
+  else gemm_persist_kernel<TC, false, true, false><<<grid, NT, 0, s>>>(g);
   return true;
 }
 
@@ -619,6 +624,21 @@ static inline bool small_grid(const GemmArgs& g) { return (int64_t)g.tiles_m * g
 template <typename T, typename TC, bool FAST, int NS>
 static int launch_gemm_ns(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
   dim3 grid(g.tiles_m * g.tiles_n, 1, g.split_k);
+  if constexpr (FAST && sizeof(T) == 2 && NS == 2) {
+    // the large-grid forward / data-gradient calls: the interior passes compiled for exactly what this call asks of them
+    if (!trans_a && g.split_k <= 1) {
+      const int epi = (!g.relu_src && !g.accumulate) ? 1 : (!g.relu_src ? 2 : (!g.accumulate ? 3 : 0));
+      if (trans_b) {
+        if (epi == 1) { gemm_kernel<T, TC, false, true, FAST, 0, NS, 1><<<grid, NT, 0, s>>>(g); return 0; }
+        if (epi == 2) { gemm_kernel<T, TC, false, true, FAST, 0, NS, 2><<<grid, NT, 0, s>>>(g); return 0; }
+        if (epi == 3) { gemm_kernel<T, TC, false, true, FAST, 0, NS, 3><<<grid, NT, 0, s>>>(g); return 0; }
+      } else {
+        if (epi == 1) { gemm_kernel<T, TC, false, false, FAST, 0, NS, 1><<<grid, NT, 0, s>>>(g); return 0; }
+        if (epi == 2) { gemm_kernel<T, TC, false, false, FAST, 0, NS, 2><<<grid, NT, 0, s>>>(g); return 0; }
+        if (epi == 3) { gemm_kernel<T, TC, false, false, FAST, 0, NS, 3><<<grid, NT, 0, s>>>(g); return 0; }
+      }
+    }
+  }
   if (!trans_a && trans_b) gemm_kernel<T, TC, false, true, FAST, 0, NS><<<grid, NT, 0, s>>>(g);
   else if (!trans_a && !trans_b) gemm_kernel<T, TC, false, false, FAST, 0, NS><<<grid, NT, 0, s>>>(g);
   else if (trans_a && !trans_b) gemm_kernel<T, TC, true, false, FAST, 0, NS><<<grid, NT, 0, s>>>(g);

@@ -111,19 +111,42 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* __restrict__ piece, int fir
 // Accumulators of one wave (8 x NI MFMA tiles = 128 rows x 16 NI columns) -> C, with bias / ReLU / ReLU-gradient gate /
 // accumulate.  Per 16 rows and 32 columns: MFMA layout -> this wave's LDS staging tile -> 8 consecutive columns per lane,
 // so that every lane stores 16 bytes (bf16) or 2 x 16 bytes (fp32) of one row.
-template <typename TC, int NI>
+// EPI (what the host guarantees, so that the unrolled chunks are straight-line code - a run-time flag in them costs 2-5 % of a
+// K = 768 problem): 0 nothing; 1 no gate, no accumulation, whole 16-byte chunks (relu_src == NULL, accumulate == 0, c_vec,
+// N % 8 == 0: the forward call of a dense layer); 2 C += with whole chunks and no gate (weight gradients): the old C of four
+// row groups is in flight ahead of the chunk that adds it, instead of one load - wait - store round trip per chunk.
+template <typename TC, int NI, int EPI>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI], const float (&bcol)[NI], float* __restrict__ Cs,
                                          int64_t wrow0, int64_t wcol0, int lane) {
   TC* C = reinterpret_cast<TC*>(g.C);
-  const bf16_t* rs = reinterpret_cast<const bf16_t*>(g.relu_src);
+  const bf16_t* rs = EPI ? nullptr : reinterpret_cast<const bf16_t*>(g.relu_src);
+  const bool accumulate = EPI ? EPI == 2 : g.accumulate != 0;
   const int lg = lane >> 4, l15 = lane & 15;
   const int rr = lane >> 2, cc = (lane & 3) * 8;
   constexpr int NH = (NI + 1) / 2;                             // 32-column halves (the last one may hold 16 columns)
+  constexpr int DEPTH = 4, NV = sizeof(TC) == 4 ? 2 : 1;
+  f32x4 oldc[EPI == 2 ? DEPTH : 1][NH][NV];
+  auto fetch_old = [&](int i) __attribute__((always_inline)) {
+    if constexpr (EPI == 2) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+      for (int jh = 0; jh < NH; ++jh) {
+        const int nj = NI - 2 * jh < 2 ? NI - 2 * jh : 2;
+        const int64_t row = wrow0 + i * 16 + rr, col = wcol0 + jh * 32 + cc;
+        if (cc >= nj * 16 || row >= g.M || col >= g.N) continue;
+        const TC* cp = C + row * g.ldc + col;
+        oldc[i % DEPTH][jh][0] = *reinterpret_cast<const f32x4*>(cp);     // 8 bf16 or the first 4 floats
+        if constexpr (NV == 2) oldc[i % DEPTH][jh][1] = *reinterpret_cast<const f32x4*>(cp + 4);
+      }
+    }
+  };
+  if constexpr (EPI == 2) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) fetch_old(i);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
 #pragma unroll
     for (int jh = 0; jh < NH; ++jh) {
-      constexpr int dummy = 0; (void)dummy;
       const int nj = NI - 2 * jh < 2 ? NI - 2 * jh : 2;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -144,15 +167,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI],
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
       const int64_t off = row * g.ldc + col;
-      if (g.c_vec && col + 8 <= g.N) {
+      if (EPI || (g.c_vec && col + 8 <= g.N)) {
         if (rs) {
           const bf16x8 m = *reinterpret_cast<const bf16x8*>(rs + off);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (float)m[e] > 0.f ? v[e] : 0.f;
         }
         if constexpr (sizeof(TC) == 2) {
-          if (g.accumulate) {
-            const bf16x8 old = *reinterpret_cast<const bf16x8*>(C + off);
+          if (accumulate) {
+            const bf16x8 old = EPI == 2 ? __builtin_bit_cast(bf16x8, oldc[i % DEPTH][jh][0]) : *reinterpret_cast<const bf16x8*>(C + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
           }
@@ -162,7 +185,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI],
           *reinterpret_cast<bf16x8*>(C + off) = o;
         } else {
           f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          if (g.accumulate) {
+          if constexpr (EPI == 2) {
+            o0 += oldc[i % DEPTH][jh][0];
+            o1 += oldc[i % DEPTH][jh][NV - 1];
+          } else if (accumulate) {
             o0 += *reinterpret_cast<const f32x4*>(C + off);
             o1 += *reinterpret_cast<const f32x4*>(C + off + 4);
           }
@@ -175,11 +201,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI],
           if (col + e >= g.N) continue;
           float x = v[e];
           if (rs) x = (float)rs[off + e] > 0.f ? x : 0.f;
-          if (g.accumulate) x += to_f32<TC>(C[off + e]);
+          if (accumulate) x += to_f32<TC>(C[off + e]);
           C[off + e] = from_f32<TC>(x);
         }
       }
     }
+    if (i + DEPTH < 8) fetch_old(i + DEPTH);                   // into the slot row group i has just released
+  }
 }
 
 // NI1 = MFMA tiles (16 columns each) per wave in the SECOND B piece: 2 -> 256-column output tiles, 1 -> 192-column tiles
@@ -187,7 +215,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[8][NI],
 // in whole rounds: N = 768 -> 252 tiles, 2304 -> 756, 1536 -> 504).
 // ONE: the workgroup computes exactly one output tile, `block` = tile row | tile column << 16 (grouped weight gradients:
 // the launch's own placement rule decides which tile a workgroup gets); otherwise the persistent static schedule below.
-template <typename TC, bool TA, bool TBK, int NI1, bool STAMPS, int ABL, bool SUMA, bool ONE = false>
+template <typename TC, bool TA, bool TBK, int NI1, bool STAMPS, int ABL, bool SUMA, bool ONE = false, int EPI = 0>
 __device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int block, const int G, unsigned long long* const stamps_buf) {
   constexpr bool AKS = TA, BKS = !TBK;                         // operand is k-strided in memory
   constexpr int NI = 2 + NI1, WN = 16 * NI, BNT = 4 * WN;      // MFMA tiles / columns per wave, columns per output tile
@@ -477,7 +505,7 @@ __device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int 
       const int64_t col = n0 + wc * WN + j * 16 + (lane & 15);
       bcol[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
     }
-    epilogue<TC, NI>(g, acc, bcol, Cs, m0 + wr * 128, n0 + wc * WN, lane);
+    epilogue<TC, NI, EPI>(g, acc, bcol, Cs, m0 + wr * 128, n0 + wc * WN, lane);
     put(4 + round * 4);
     // the stores above are younger than the pieces in flight: drain everything, so that the counted waits of the next
     // tile's first phases again count only pieces
@@ -489,9 +517,9 @@ __device__ __forceinline__ void body(const GemmArgs& g, const int nk, const int 
   if constexpr (STAMPS) { put(21); if (tid == 0 && stamps_buf) stamp[22] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-template <typename TC, bool TA, bool TBK, int NI1 = 2, bool STAMPS = false, int ABL = 0, bool SUMA = false>
+template <typename TC, bool TA, bool TBK, int NI1 = 2, bool STAMPS = false, int ABL = 0, bool SUMA = false, int EPI = 0>
 __global__ void __launch_bounds__(NT, 2) gemm256_kernel(Args args) {
-  body<TC, TA, TBK, NI1, STAMPS, ABL, SUMA>(args.g, args.nk, blockIdx.x, gridDim.x, args.stamps);
+  body<TC, TA, TBK, NI1, STAMPS, ABL, SUMA, false, EPI>(args.g, args.nk, blockIdx.x, gridDim.x, args.stamps);
 }
 
 // Several weight gradients in ONE launch: C_i[M_i, N_i] += A_i^T . B_i with A_i [K_i][M_i] (dY), B_i [K_i][N_i] (X), fp32 C,
@@ -524,7 +552,7 @@ __global__ void __launch_bounds__(NT, 2) gemm256_group_kernel(GroupArgs ga) {
   int tm, tn;
   if (g.tiles_m <= g.tiles_n) { tm = lt % g.tiles_m; tn = lt / g.tiles_m; }
   else { tn = lt % g.tiles_n; tm = lt / g.tiles_n; }
-  body<float, true, false, 1, false, 0, true, true>(g, ga.nk[pi], tm | (tn << 16), 8, nullptr);
+  body<float, true, false, 1, false, 0, true, true, 2>(g, ga.nk[pi], tm | (tn << 16), 8, nullptr);
 }
 
 }  // namespace t2
@@ -604,7 +632,10 @@ static void launch256(const GemmArgs& g0, int trans_a, int trans_b, hipStream_t 
   if constexpr (sizeof(TC) == 4) {
     if (g0.opsum) { t2::gemm256_kernel<TC, true, false, NI1, false, 0, true><<<grid, t2::NT, 0, s>>>(a); return; }
   }
-  if (!trans_a && trans_b) t2::gemm256_kernel<TC, false, true, NI1><<<grid, t2::NT, 0, s>>>(a);
+  const bool plain = !g0.relu_src && !g0.accumulate && g0.c_vec && g0.N % 8 == 0;      // EPI 1: see t2::epilogue
+  if (!trans_a && trans_b && plain) t2::gemm256_kernel<TC, false, true, NI1, false, 0, false, 1><<<grid, t2::NT, 0, s>>>(a);
+  else if (!trans_a && !trans_b && plain) t2::gemm256_kernel<TC, false, false, NI1, false, 0, false, 1><<<grid, t2::NT, 0, s>>>(a);
+  else if (!trans_a && trans_b) t2::gemm256_kernel<TC, false, true, NI1><<<grid, t2::NT, 0, s>>>(a);
   else if (!trans_a && !trans_b) t2::gemm256_kernel<TC, false, false, NI1><<<grid, t2::NT, 0, s>>>(a);
   else if (trans_a && !trans_b) t2::gemm256_kernel<TC, true, false, NI1><<<grid, t2::NT, 0, s>>>(a);
   else t2::gemm256_kernel<TC, true, true, NI1><<<grid, t2::NT, 0, s>>>(a);
@@ -624,6 +655,7 @@ int64_t neurst_gemm256_group_tiles(int64_t M, int64_t N) { return cdiv64(M, t2::
 // inside one (tile, K-tile) window, tile coordinates that fit the packed block id.
 bool neurst_gemm256_group_eligible(const GemmArgs& g) {
   if (!g.a_aligned || !g.b_aligned || g.M % 8 || g.N % 8) return false;
+  if (!g.c_vec || !g.accumulate || g.relu_src || g.relu || g.bias) return false;   // its epilogue is C += in whole 16-byte chunks and nothing else
   if ((64 * g.lda + 256) * 2 >= 0x7fff0000ll || (64 * g.ldb + 256) * 2 >= 0x7fff0000ll) return false;
   if (cdiv64(g.M, t2::BM) > 0xffff || cdiv64(g.N, 192) > 0x7fff) return false;
   return true;

@@ -147,11 +147,15 @@ __device__ __forceinline__ void issue_glds(const T* __restrict__ base, int64_t l
 constexpr int PEPI_LD = 36;                                   // fp32 row stride of a 16 x 32 staging half-tile
 constexpr int PEPI_BYTES = 4 * 16 * PEPI_LD * 4;              // one per wave
 
-template <typename T, typename TC, int MI = 4>
+// SIMPLE: the forward call of a dense layer and nothing else - no gate, no accumulation, whole 16-byte chunks (the host checks
+// relu_src == NULL, accumulate == 0, c_vec and N % 8 == 0) - so the unrolled chunks are straight-line code with one row test each
+template <typename T, typename TC, int MI = 4, bool SIMPLE = false>
 __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][4], const float (&bcol)[4], float* __restrict__ Cs,
                                                  int64_t wrow0, int64_t wcol0, int lane) {
   TC* C = reinterpret_cast<TC*>(g.C);
-  const T* rs = reinterpret_cast<const T*>(g.relu_src);
+  const T* rs = SIMPLE ? nullptr : reinterpret_cast<const T*>(g.relu_src);
+  const bool accumulate = SIMPLE ? false : g.accumulate != 0;
+  const bool c_vec = SIMPLE ? true : g.c_vec != 0;
   const int lg = lane >> 4, l15 = lane & 15;
   const int rr = lane >> 2, cc = (lane & 3) * 8;
   // relu-gradient gate: all eight chunks this lane needs are requested up front (one wait instead of eight)
@@ -160,7 +164,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
     for (int p = 0; p < 2 * MI; ++p) {
       const int64_t row = wrow0 + (p >> 1) * 16 + rr, col = wcol0 + (p & 1) * 32 + cc;
-      if (row < g.M && g.c_vec && col + 8 <= g.N) gate[p] = *reinterpret_cast<const typename Chunk<T>::V*>(rs + row * g.ldc + col);
+      if (row < g.M && c_vec && col + 8 <= g.N) gate[p] = *reinterpret_cast<const typename Chunk<T>::V*>(rs + row * g.ldc + col);
     }
   }
 #pragma unroll
@@ -185,14 +189,14 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
       const int64_t off = row * g.ldc + col;
-      if (g.c_vec && col + 8 <= g.N) {
+      if (SIMPLE || (c_vec && col + 8 <= g.N)) {
         if (rs) {
           const typename Chunk<T>::V m = gate[i * 2 + jh];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = to_f32<T>(m[e]) > 0.f ? v[e] : 0.f;
         }
         if constexpr (sizeof(TC) == 2) {
-          if (g.accumulate) {
+          if (accumulate) {
             const bf16x8 old = *reinterpret_cast<const bf16x8*>(C + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
@@ -203,7 +207,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
           STORE_C(reinterpret_cast<bf16x8*>(C + off), o);
         } else {
           f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          if (g.accumulate) {
+          if (accumulate) {
             o0 += *reinterpret_cast<const f32x4*>(C + off);
             o1 += *reinterpret_cast<const f32x4*>(C + off + 4);
           }
@@ -216,7 +220,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmArgs& g, f32x4 (&acc)
           if (col + e >= g.N) continue;
           float x = v[e];
           if (rs) x = to_f32<T>(rs[off + e]) > 0.f ? x : 0.f;
-          if (g.accumulate) x += to_f32<TC>(C[off + e]);
+          if (accumulate) x += to_f32<TC>(C[off + e]);
           C[off + e] = from_f32<TC>(x);
         }
       }

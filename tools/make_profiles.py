@@ -28,20 +28,26 @@ def gemm_label(name):
     if m2:
         lay = {('false', 'true'): 'NT', ('false', 'false'): 'NN', ('true', 'false'): 'TN', ('true', 'true'): 'TT'}[m2.groups()[1:]]
         return 'gemm256_kernel<bf16,%s,%s>' % ('f32' if m2.group(1) == 'float' else 'bf16', lay)
-    mp = re.match(r'_Z19gemm_persist_kernelI(DF16b|f)Lb([01])ELb([01])EEv8GemmArgs', name)
+    # (the instantiations of one label differ in their last template arguments: what the epilogue knows at compile time)
+    mp = re.match(r'_Z19gemm_persist_kernelI(DF16b|f)Lb([01])ELb([01])E(?:Lb[01]E)?Ev8GemmArgs', name)
     if mp:
         lay = {('0', '1'): 'NT', ('0', '0'): 'NN', ('1', '0'): 'TN'}[mp.groups()[1:]]
         return 'gemm_persist_kernel<bf16,%s,%s>' % ('bf16' if mp.group(1) == 'DF16b' else 'f32', lay)
-    mt = re.match(r'_Z16gemm_thin_kernelI(DF16b|f)Lb([01])EEv8GemmArgs', name)
+    mp = re.match(r'void gemm_persist_kernel<(float|bool _Accum|__bf16), (true|false), (true|false)', name)
+    if mp:
+        lay = {('false', 'true'): 'NT', ('false', 'false'): 'NN', ('true', 'false'): 'TN'}[mp.groups()[1:]]
+        return 'gemm_persist_kernel<bf16,%s,%s>' % ('f32' if mp.group(1) == 'float' else 'bf16', lay)
+    mt = re.match(r'_Z16gemm_thin_kernelI(DF16b|f)Lb([01])E(?:Lb[01]E)?Ev8GemmArgs', name)
     if mt:
         return 'gemm_thin_kernel<bf16,%s,%s>' % ('bf16' if mt.group(1) == 'DF16b' else 'f32', 'NT' if mt.group(2) == '1' else 'NN')
-    if name.startswith('void gemm_thin_kernel<bool _Accum, bool'):   # rocprofv3's half-demangled spelling of <bf16, true> (the NN one stays mangled)
-        return 'gemm_thin_kernel<bf16,bf16,NT>'
-    m = re.match(r'_Z11gemm_kernelI(DF16b|f)(DF16b|f)Lb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)EEv8GemmArgs', name)
+    mt = re.match(r'void gemm_thin_kernel<(float|bool _Accum|__bf16), (true|false|bool)', name)   # rocprofv3's half-demangled spellings
+    if mt:
+        return 'gemm_thin_kernel<bf16,%s,%s>' % ('f32' if mt.group(1) == 'float' else 'bf16', 'NN' if mt.group(2) == 'false' else 'NT')
+    m = re.match(r'_Z11gemm_kernelI(DF16b|f)(DF16b|f)Lb([01])ELb([01])ELb([01])ELi(\d)ELi(\d)E(?:Li\dE)?Ev8GemmArgs', name)
     if m:
         t, tc, ta, tbk, fast, sumop, ns = m.groups()
     else:
-        m = re.match(r'void gemm_kernel<bool _Accum, (true|false), (true|false), (true|false), (\d), (\d)>', name)
+        m = re.match(r'void gemm_kernel<bool _Accum, (true|false), (true|false), (true|false), (\d), (\d)(?:, \d)?>', name)
         if not m:
             return None
         t, tc = 'DF16b', 'f'
