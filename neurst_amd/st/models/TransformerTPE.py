@@ -166,7 +166,7 @@ class TransformerTPE(Seq2SeqModel):
             # With the host running ahead, the decoder's and the semantic encoder's weight gradients (2560 and ~1024 rows, 66
             # launches of 20-40 us that occupy 36-144 CUs each) go out as whole-K tiles of the grouped kernel on the second
             # stream instead: 11.98 -> 10.36 ms/step from the second stream alone, 10.10 with the groups (LUT, whose decoder
-            # has 1280 rows, measured slower with them: 13.15 -> 13.71, and keeps the 8192-row threshold)
+            # has 1280 rows, measured slower with them: 13.15 -> 13.71, and keeps the default threshold between its encoder and decoder rows)
             self.graph.group_min_rows = 1024
         self.graph.on_param_grad = self.bucketer.param_done
         self.graph.on_node_done = self.bucketer.node_done

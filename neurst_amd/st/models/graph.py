@@ -266,8 +266,10 @@ class Graph:
         # NEURST_GROUP_WGRAD=0 turns it off (one split-K launch per gradient).
         self.group_wgrads = os.environ.get('NEURST_GROUP_WGRAD', '1') != '0'
         # decoder-size gradients (1280 rows) grouped as well: measured 13.93 -> 14.43 ms per step (every flush that an in-place
-        # update forces makes the main stream wait for a whole-K launch), so only encoder-size layers take part
-        self.group_min_rows = int(os.environ.get('NEURST_GROUP_MIN_ROWS', '8192'))
+        # update forces makes the main stream wait for a whole-K launch), so only encoder-size layers take part.  The line sits
+        # between the two at every batch size in use: 3072 rows = 7 utterances of 500 frames or 77 label rows of 40 (it was
+        # 8192 until 16 utterances - 8000 rows - turned out to fall under it: 9.65 -> 9.08 ms per step there, 7.21 -> 6.41 at 8)
+        self.group_min_rows = int(os.environ.get('NEURST_GROUP_MIN_ROWS', '3072'))
         self.group_launch_tiles = int(os.environ.get('NEURST_GROUP_TILES', '256'))
         self.pending_wgrads = []
         self.pending_tiles = 0
