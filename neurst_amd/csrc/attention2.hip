@@ -601,7 +601,9 @@ struct FwdArgs {
   float qscale, keep_scale;
 };
 
-template <int DH, bool DROP, int ABL = 0>
+// READY: the keep bitmap already holds the decisions (a.keep_ready, checked by the host): they are loaded, not drawn.  A template
+// argument, not a run-time flag: the loop body then holds one of the two paths instead of both.
+template <int DH, bool DROP, int ABL = 0, bool READY = false>
 __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
   typedef LdsF<DH> L;
   constexpr int ROWB = DH * 2;
@@ -658,7 +660,7 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
       kwn[pr] = (ok && wi < a.nw) ? a.keep[rg * a.nw + wi] : 0u;
     }
   };
-  if constexpr (DROP) { if (a.keep_ready) load_kw(0, 0); }
+  if constexpr (DROP && READY) load_kw(0, 0);
   issue_block(0, 0);
   int it = 0;                                                             // blocks consumed so far (buffer = it & 1)
   for (int grp = 0; grp < ngroup; ++grp) {
@@ -691,7 +693,7 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
         const bool more = kb + 1 < nkb || grp + 1 < ngroup;
         if constexpr (DROP) {
           asm volatile("" : "+v"(kwc0), "+v"(kwc1));                      // their use stays in front of the next loads and DMA pieces
-          if (a.keep_ready && more) load_kw(kb + 1 < nkb ? grp : grp + 1, nkb_next);
+          if (READY && more) load_kw(kb + 1 < nkb ? grp : grp + 1, nkb_next);
         }
         if (more) issue_block(nkb_next, (it + 1) & 1);
       }
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
         if constexpr (DROP) {
           const int wi = kb * (KBF / 32) + 2 * pr + g;
           uint32_t mine;
-          if (a.keep_ready) {                                             // wave-uniform
+          if constexpr (READY) {
             mine = pr == 0 ? kwc0 : kwc1;
           } else {
             mine = attn_keep_word(a.key, a.inner0, a.idx32, (uint64_t)(row_g * a.nw + wi), a.t16);
@@ -939,8 +941,9 @@ int neurst_mha2_fwd_launch(const Mha2FwdProblem& p, hipStream_t s) {
   a.qscale = 1.0f / sqrtf((float)p.dh);
   a.keep_scale = keep_scale(p.rate);
   const size_t smem = p.dh == 96 ? a2::LdsF<96>::BYTES : a2::LdsF<64>::BYTES;
-  auto kern = p.rate > 0.f ? a2::mha2_fwd_kernel<96, true> : a2::mha2_fwd_kernel<96, false>;
-  if (p.dh == 64) kern = p.rate > 0.f ? a2::mha2_fwd_kernel<64, true> : a2::mha2_fwd_kernel<64, false>;
+  const bool ready = a.keep_ready != 0;
+  auto kern = p.rate > 0.f ? (ready ? a2::mha2_fwd_kernel<96, true, 0, true> : a2::mha2_fwd_kernel<96, true>) : a2::mha2_fwd_kernel<96, false>;
+  if (p.dh == 64) kern = p.rate > 0.f ? (ready ? a2::mha2_fwd_kernel<64, true, 0, true> : a2::mha2_fwd_kernel<64, true>) : a2::mha2_fwd_kernel<64, false>;
   else switch (g_opt_fwd_ablate) {
     case 1: kern = a2::mha2_fwd_kernel<96, false, 1>; break;
     case 2: kern = a2::mha2_fwd_kernel<96, false, 2>; break;
