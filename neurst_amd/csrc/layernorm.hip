@@ -455,12 +455,250 @@ __global__ void ln_bwd_generic(const T* __restrict__ dout, const T* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ straight-line kernels for the training shapes
+// bf16 rows of exactly 64 NCH VEC columns (768 = 64 x 3 x 4, 512 = 64 x 1 x 8, 256 = 64 x 1 x 4), 32-bit element indices, no
+// row mask, column sums by atomics: everything the general kernels decide per element or per chunk at run time (lane in range?
+// dropout on? 32- or 64-bit hash? row masked?) is known here when the kernel is compiled, so a row is ONE basic block.  That
+// matters beyond the branch instructions: hipcc places exact vmcnt waits only inside a basic block - across the general
+// kernels' per-chunk branches every wait was vmcnt(0), i.e. the next row's loads also waited for this row's stores.
+// The next row (and its mean / rstd) is requested before this row's stores go out; its index is clamped instead of tested.
+// The next rows are requested by inline-assembly loads in program order and awaited by COUNTED waits written here (hipcc moved
+// its own loads of the next row below the current row's work, or made their first use wait for everything): when a register
+// set is first read, the only younger vector-memory operations are the other set's stores and its refill, and exactly those
+// may stay outstanding.  The counts rely on the compiler issuing nothing else through the vector-memory counter inside the row
+// loop - no scratch traffic (checked: private_segment size 0 for every instantiation) and one store per chunk.
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2_t;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
+template <int VEC> struct LineRaw;
+template <> struct LineRaw<4> {
+  typedef bf16x4 T;
+  typedef u32x2_t R;
+  template <int OFF> static __device__ __forceinline__ void load(R& r, const bf16_t* p) {   // OFF: byte offset, an immediate
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+  }
+};
+template <> struct LineRaw<8> {
+  typedef bf16x8 T;
+  typedef u32x4_t R;
+  template <int OFF> static __device__ __forceinline__ void load(R& r, const bf16_t* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+  }
+};
+// chunk c of a row sits 64 VEC elements behind chunk c - 1: one address register pair per tensor, the rest in the instruction
+template <int VEC, int NCH, int c = 0, typename Raw>
+__device__ __forceinline__ void line_fetch(Raw (&f)[NCH], const bf16_t* p) {
+  if constexpr (c < NCH) {
+    LineRaw<VEC>::template load<c * 64 * VEC * 2>(f[c], p);
+    line_fetch<VEC, NCH, c + 1>(f, p);
+  }
+}
+#define LN_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// (no __restrict__ on these kernels' pointers: with it, alias analysis lets the compiler move its stores across the inline-assembly
+// loads - "they cannot touch the same memory" - and the counted waits would then count operations that are not there yet)
+template <int VEC, int NCH, bool DROP>
+__global__ void __launch_bounds__(256) ln_fwd_line(const bf16_t* x, bf16_t* yz, const float* gamma,
+                                                    const float* beta, bf16_t* out, float* mean,
+                                                    float* rstd, int64_t rows, uint32_t thr, float scale, uint32_t inner0) {
+  typedef typename LineRaw<VEC>::T Vec;
+  typedef typename LineRaw<VEC>::R Raw;
+  constexpr int C = 64 * NCH * VEC;
+  constexpr float invC = 1.f / (float)C;
+  constexpr int NL = 2 * NCH, NS = 2 * NCH + 2;              // loads of a fetch; stores of a row (z, out, mean, rstd)
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float gv[NCH][VEC], bv[NCH][VEC];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const f32x4 tg = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * c) * VEC + 4 * q);
+      const f32x4 tb = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * c) * VEC + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gv[c][4 * q + e] = tg[e]; bv[c][4 * q + e] = tb[e]; }
+    }
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  Raw ax[NCH], ay[NCH], bx[NCH], by[NCH];                    // two register sets: one worked on, one being filled
+  auto fetch = [&](Raw (&fx)[NCH], Raw (&fy)[NCH], int64_t r) __attribute__((always_inline)) {
+    line_fetch<VEC, NCH>(fx, x + r * C + lane * VEC);
+    line_fetch<VEC, NCH>(fy, yz + r * C + lane * VEC);
+  };
+  auto work = [&](Raw (&rx)[NCH], Raw (&ry)[NCH], int64_t r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(rx[c]), "+v"(ry[c]));      // read only behind the wait above
+    float z[NCH][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const Vec cx = __builtin_bit_cast(Vec, rx[c]), cy = __builtin_bit_cast(Vec, ry[c]);
+      const uint32_t off = (uint32_t)(r * C) + (lane + 64 * c) * VEC;
+      Vec zr;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float yy = (float)cy[j];
+        if constexpr (DROP) yy = (fmix32((off + j) ^ inner0) >> 8) >= thr ? yy * scale : 0.f;
+        zr[j] = (bf16_t)((float)cx[j] + yy);                 // the residual sum is rounded to the activation type, as stored
+        z[c][j] = (float)zr[j];
+        s += z[c][j];
+      }
+      *reinterpret_cast<Vec*>(yz + r * C + (lane + 64 * c) * VEC) = zr;
+    }
+    const float mu = wave_sum_dpp(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float d = z[c][j] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum_dpp(q) * invC + LN_EPS);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      Vec o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = (bf16_t)(((z[c][j] - mu) * rs) * gv[c][j] + bv[c][j]);
+      *reinterpret_cast<Vec*>(out + r * C + (lane + 64 * c) * VEC) = o;
+    }
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+  };
+  // rows of this wave: row + k nwaves, k < n; a request past the end asks for the last row again (harmless)
+  const int64_t n = (rows - row + nwaves - 1) / nwaves;
+  auto rowk = [&](int64_t k) { return row + (k < n ? k : n - 1) * nwaves; };
+  fetch(ax, ay, row);
+  fetch(bx, by, rowk(1));
+  LN_WAIT(NL);                                               // the first row is here (gamma / beta were requested before it)
+  work(ax, ay, row);
+  int64_t k = 1;
+  for (; k + 1 < n; k += 2) {
+    fetch(ax, ay, rowk(k + 1));
+    LN_WAIT(NS + NL);                                        // younger than set B: the stores of the row before, the refill of set A
+    work(bx, by, rowk(k));
+    fetch(bx, by, rowk(k + 2));
+    LN_WAIT(NS + NL);
+    work(ax, ay, rowk(k + 1));
+  }
+  if (k < n) {
+    LN_WAIT(0);
+    work(bx, by, rowk(k));
+  }
+  LN_WAIT(0);                                                // requests past the end still in flight: their registers are dead, but land them
+}
+
+template <int VEC, int NCH, bool DROP>
+__global__ void __launch_bounds__(1024) ln_bwd_line(const bf16_t* dout, const bf16_t* z, const float* gamma,
+                                                    const float* mean, const float* rstd, bf16_t* dz,
+                                                    bf16_t* dy, float* dgamma, float* dbeta,
+                                                    int64_t rows, uint32_t thr, float scale, uint32_t inner0) {
+  typedef typename LineRaw<VEC>::T Vec;
+  typedef typename LineRaw<VEC>::R Raw;
+  constexpr int C = 64 * NCH * VEC;
+  constexpr float invC = 1.f / (float)C;
+  constexpr int NL = 2 * NCH + 2, NS = NCH * (DROP ? 2 : 1);   // loads of a fetch (dout, z, mean, rstd); stores of a row
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sm = reinterpret_cast<float*>(smem_raw);          // [2][nw][C]
+  const int nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float dgam[NCH][VEC], dbet[NCH][VEC], gv[NCH][VEC];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const f32x4 tg = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * c) * VEC + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gv[c][4 * q + e] = tg[e]; dgam[c][4 * q + e] = 0.f; dbet[c][4 * q + e] = 0.f; }
+    }
+  const int64_t rstride = (int64_t)gridDim.x * nw;
+  const int64_t row = (int64_t)blockIdx.x * nw + w;
+  if (row < rows) {
+    Raw ad[NCH], az[NCH], bd[NCH], bz[NCH];
+    uint32_t amu, ars, bmu, brs;                             // the row's mean and rstd ride with its fetch (a compiler-issued load
+                                                             // here would be waited for with vmcnt(0): the refill with it)
+    auto fetch = [&](Raw (&fd)[NCH], Raw (&fz)[NCH], uint32_t& fmu, uint32_t& frs, int64_t r) __attribute__((always_inline)) {
+      asm volatile("global_load_dword %0, %1, off" : "=v"(fmu) : "v"(mean + r) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(frs) : "v"(rstd + r) : "memory");
+      line_fetch<VEC, NCH>(fd, dout + r * C + lane * VEC);
+      line_fetch<VEC, NCH>(fz, z + r * C + lane * VEC);
+    };
+    auto work = [&](Raw (&rd)[NCH], Raw (&rz)[NCH], uint32_t& rmu, uint32_t& rrs, int64_t r) __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(rd[c]), "+v"(rz[c]));
+      asm volatile("" : "+v"(rmu), "+v"(rrs));
+      const float mu = __builtin_bit_cast(float, rmu), rs = __builtin_bit_cast(float, rrs);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const Vec cd = __builtin_bit_cast(Vec, rd[c]), cz = __builtin_bit_cast(Vec, rz[c]);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float d = (float)cd[j], xh = ((float)cz[j] - mu) * rs, gg = d * gv[c][j];
+          dgam[c][j] += d * xh;
+          dbet[c][j] += d;
+          s1 += gg;
+          s2 += gg * xh;
+        }
+      }
+      const float m1 = wave_sum_dpp(s1) * invC, m2 = wave_sum_dpp(s2) * invC;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const Vec cd = __builtin_bit_cast(Vec, rd[c]), cz = __builtin_bit_cast(Vec, rz[c]);
+        const uint32_t off = (uint32_t)(r * C) + (lane + 64 * c) * VEC;
+        Vec o, od;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float d = (float)cd[j], xh = ((float)cz[j] - mu) * rs, gg = d * gv[c][j];
+          const float v = rs * (gg - m1 - xh * m2);
+          o[j] = (bf16_t)v;
+          if constexpr (DROP) od[j] = (bf16_t)((fmix32((off + j) ^ inner0) >> 8) >= thr ? v * scale : 0.f);
+        }
+        *reinterpret_cast<Vec*>(dz + r * C + (lane + 64 * c) * VEC) = o;
+        if constexpr (DROP) *reinterpret_cast<Vec*>(dy + r * C + (lane + 64 * c) * VEC) = od;
+      }
+    };
+    const int64_t n = (rows - row + rstride - 1) / rstride;  // see ln_fwd_line
+    auto rowk = [&](int64_t k) { return row + (k < n ? k : n - 1) * rstride; };
+    fetch(ad, az, amu, ars, row);
+    fetch(bd, bz, bmu, brs, rowk(1));
+    LN_WAIT(NL);
+    work(ad, az, amu, ars, row);
+    int64_t k = 1;
+    for (; k + 1 < n; k += 2) {
+      fetch(ad, az, amu, ars, rowk(k + 1));
+      LN_WAIT(NS + NL);
+      work(bd, bz, bmu, brs, rowk(k));
+      fetch(bd, bz, bmu, brs, rowk(k + 2));
+      LN_WAIT(NS + NL);
+      work(ad, az, amu, ars, rowk(k + 1));
+    }
+    if (k < n) {
+      LN_WAIT(0);
+      work(bd, bz, bmu, brs, rowk(k));
+    }
+    LN_WAIT(0);
+  }
+  // block reduction of the per-wave column partials, then a few hundred atomic adds per address over the grid
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      sm[(0 * nw + w) * C + (lane + 64 * c) * VEC + j] = dgam[c][j];
+      sm[(1 * nw + w) * C + (lane + 64 * c) * VEC + j] = dbet[c][j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int which = i / C, col = i % C;
+    float s = 0.f;
+    for (int ww = 0; ww < nw; ++ww) s += sm[(which * nw + ww) * C + col];
+    atomicAdd((which ? dbeta : dgamma) + col, s);
+  }
+}
+
 // ------------------------------------------------------------------ host side
 // neurst_set_option("ln_prefetch", bits): 1 = forward, 2 = backward row loop with the next row requested ahead of the stores.
 // Measured on 16000 x 768 bf16, rate 0.1 (tools/bench_kernels.py ln, launch overhead included): forward 31.0 -> 29.6 us;
 // backward 33.6 -> 37.6 us - its 16-wave workgroups get 128 registers per lane and the 16 registers of the packed next row
 // push the column-sum accumulators into scratch inside the loop - so only the forward takes it by default.
-int g_opt_ln_prefetch = [] { const char* e = getenv("NEURST_LN_PREFETCH"); return e ? atoi(e) : 5; }();
+int g_opt_ln_prefetch = [] { const char* e = getenv("NEURST_LN_PREFETCH"); return e ? atoi(e) : 53; }();
 // bits 4 / 8 of the same option: forward / backward take 8-byte lanes when a bf16 row is whole wave passes of them but not of
 // 16-byte lanes (C = 768: 3 x 64 x 4 against 1.5 x 64 x 8).  Measured at 16000 x 768, rate 0.1: forward 28.4 -> 26.8 us alone and
 // 0.392 -> 0.373 ms per step; the backward 32.2 -> 30.9 us alone but 0.510 -> 0.537 ms inside the step (same box, alternating
@@ -469,6 +707,10 @@ static inline bool ln_lanes8(int64_t C, int bit) {
   return (g_opt_ln_prefetch & bit) && C % 256 == 0 && C % 512 != 0 && C / 256 <= 4;
 }
 static inline int ln_nch(int64_t C, int vec) { return (int)cdiv64(C / vec, 64); }
+// bits 16 / 32: forward / backward of the training shapes through the straight-line kernels (ln_fwd_line / ln_bwd_line)
+// (not 1024 = 64 x 2 x 8: its backward needs more than the 128 registers a 16-wave workgroup has, and scratch traffic would
+// break the kernels' wait counts)
+static inline bool ln_line_shape(int64_t C) { return C == 256 || C == 512 || C == 768; }
 static inline bool ln_vec_ok(int64_t C, int vec, const void* a, const void* b, const void* c) {
   return C % vec == 0 && ln_nch(C, vec) <= 8 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0) && C % 4 == 0;
 }
@@ -517,7 +759,18 @@ extern "C" int neurst_dropout_add_layernorm_fwd(const void* x, void* yz, const f
     case 4: FWD_VEC(TT, VEC, 4); break;                               \
     default: FWD_VEC(TT, VEC, 8); break;                              \
   }
-  if (dtype == NEURST_BF16) {
+  if (dtype == NEURST_BF16 && (g_opt_ln_prefetch & 16) && !lens && idx32 && ln_line_shape(C) &&
+      ((((uintptr_t)x | (uintptr_t)yz | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0)) {
+#define FWD_LINE(VEC, NCH)                                                                                                           \
+    if (thr) ln_fwd_line<VEC, NCH, true><<<gv_, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)yz, gamma, beta, (bf16_t*)out, mean, rstd, rows, thr, sc, inner0); \
+    else ln_fwd_line<VEC, NCH, false><<<gv_, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)yz, gamma, beta, (bf16_t*)out, mean, rstd, rows, thr, sc, inner0)
+    switch ((int)C) {
+      case 256: FWD_LINE(4, 1); break;
+      case 512: FWD_LINE(8, 1); break;
+      default: FWD_LINE(4, 3); break;
+    }
+#undef FWD_LINE
+  } else if (dtype == NEURST_BF16) {
     if (ln_vec_ok(C, 8, x, yz, out)) { if (ln_lanes8(C, 4)) { FWD_DISPATCH(bf16_t, 4) } else { FWD_DISPATCH(bf16_t, 8) } }
     else ln_fwd_generic<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)yz, gamma, beta, (bf16_t*)out, mean, rstd, rows, (int)C, thr, sc, key, lens, T);
   } else {
@@ -566,6 +819,26 @@ extern "C" int neurst_dropout_add_layernorm_bwd(const void* dout, const void* z,
     case 3: BWD_VEC(TT, VEC, 3); break;                               \
     case 4: BWD_VEC(TT, VEC, 4); break;                               \
     default: BWD_VEC(TT, VEC, 8); break;                              \
+  }
+  if (dtype == NEURST_BF16 && (g_opt_ln_prefetch & 32) && !lens && idx32 && !use_partial && !dbias && ln_line_shape(C) &&
+      ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)gamma | (thr ? (uintptr_t)dy : 0)) & 15) == 0)) {
+    const size_t lsm = (size_t)2 * (nthr / 64) * C * sizeof(float);
+#define BWD_LINE(VEC, NCH)                                                                                                           \
+    if (thr) {                                                                                                                       \
+      if (lsm > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_line<VEC, NCH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsm); \
+      ln_bwd_line<VEC, NCH, true><<<grid, nthr, lsm, s>>>((const bf16_t*)dout, (const bf16_t*)z, gamma, mean, rstd, (bf16_t*)dz, (bf16_t*)dy, dgamma, dbeta, rows, thr, sc, inner0); \
+    } else {                                                                                                                         \
+      if (lsm > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_line<VEC, NCH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsm); \
+      ln_bwd_line<VEC, NCH, false><<<grid, nthr, lsm, s>>>((const bf16_t*)dout, (const bf16_t*)z, gamma, mean, rstd, (bf16_t*)dz, (bf16_t*)dy, dgamma, dbeta, rows, thr, sc, inner0); \
+    }
+    switch ((int)C) {
+      case 256: BWD_LINE(4, 1); break;
+      case 512: BWD_LINE(8, 1); break;
+      default: BWD_LINE(4, 3); break;
+    }
+#undef BWD_LINE
+    NEURST_CHECK_LAUNCH("dropout_add_layernorm_bwd");
+    return NEURST_OK;
   }
   if (dtype == NEURST_BF16) {
     if (ln_vec_ok(C, 8, dout, z, dz) && (!thr || ((uintptr_t)dy & 15) == 0) && shmem <= 150 * 1024) { vec = true; if (ln_lanes8(C, 8)) { BWD_DISPATCH(bf16_t, 4) } else { BWD_DISPATCH(bf16_t, 8) } }

@@ -1,5 +1,6 @@
 """-m gpu: every HIP kernel through the C ABI against the numpy oracle on the same seeded inputs.
 fp32 mode: 1e-5 relative (north_star); bf16 mode: the tolerance stated per test."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -20,6 +21,9 @@ def dev(a, dtype=None):
 
 def host(t):
     return t.float().cpu().numpy() if t.dtype in (torch.bfloat16, torch.float32) else t.cpu().numpy()
+
+
+LN_DEFAULT = int(os.environ.get('NEURST_LN_PREFETCH', '53'))     # csrc/layernorm.hip: g_opt_ln_prefetch
 
 
 def relerr(a, b):
@@ -447,6 +451,36 @@ def test_dropout_add_layernorm(dtype, tol, C, rate):
     assert relerr(host(dg2), dg_ref) < tol and relerr(host(db2), db_ref) < tol
 
 
+@pytest.mark.parametrize('rate', [0.1, 0.0])
+@pytest.mark.parametrize('rows', [16000, 1, 37, 4096 + 3])
+@pytest.mark.parametrize('C', [768, 512, 256])
+def test_layernorm_straight_line_kernels_agree_with_the_general_ones(C, rows, rate):
+    """ln_prefetch bits 16 / 32: ln_fwd_line / ln_bwd_line (rows of 64 x NCH x VEC columns, no row mask; loads by inline assembly
+    two rows ahead with counted waits) against the general vector kernels on the same inputs: same dropout decisions (the residual sum
+    is bit-identical), statistics and column sums to fp32 rounding, bf16 outputs to one rounding step.  Row counts around the waves'
+    strides: one row, fewer rows than waves, an odd number of rows per wave."""
+    rng = np.random.default_rng(C + rows)
+    key = O.site_key(5, 9, 1)
+    x = dev(bf16_round(rng.standard_normal((rows, C)).astype(np.float32)), torch.bfloat16)
+    y0 = dev(bf16_round(rng.standard_normal((rows, C)).astype(np.float32)), torch.bfloat16)
+    dout = dev(bf16_round(rng.standard_normal((rows, C)).astype(np.float32)), torch.bfloat16)
+    gam, bet = dev((1 + 0.1 * rng.standard_normal(C)).astype(np.float32)), dev((0.1 * rng.standard_normal(C)).astype(np.float32))
+    res = {}
+    try:
+        for bits in (0, 48):
+            ops.set_option('ln_prefetch', bits)
+            yz = y0.clone()
+            out, mean, rstd = ops.dropout_add_layernorm_fwd(x, yz, gam, bet, rate, key)
+            dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dz, dy = ops.dropout_add_layernorm_bwd(dout, yz, gam, mean, rstd, dg, db, rate, key)
+            res[bits] = [host(t) for t in (out, yz, mean, rstd, dz, dy, dg, db)]
+    finally:
+        ops.set_option('ln_prefetch', LN_DEFAULT)
+    for i, (a, b) in enumerate(zip(res[0], res[48])):
+        assert relerr(b, a) < (2e-5 if i in (2, 3, 6, 7) else 4e-3), i
+    assert np.array_equal(res[0][1], res[48][1])
+
+
 @pytest.mark.parametrize('C', [768, 256])
 def test_layernorm_lane_widths_and_prefetch_agree(C):
     """ln_prefetch bits (1 / 2: next row requested ahead of the stores, 4 / 8: 8-byte lanes for rows that are whole wave passes of
@@ -468,7 +502,7 @@ def test_layernorm_lane_widths_and_prefetch_agree(C):
             dz, dy = ops.dropout_add_layernorm_bwd(dout, yz, gam, mean, rstd, dg, db, rate, key, lens, T)
             res[bits] = [host(t) for t in (out, yz, mean, rstd, dz, dy, dg, db)]
     finally:
-        ops.set_option('ln_prefetch', 5)
+        ops.set_option('ln_prefetch', LN_DEFAULT)
     # another lane layout sums a row in another order, and hipcc contracts the two loop shapes into different fma chains:
     # statistics and column sums agree to fp32 rounding, bf16 outputs to one rounding step; the residual sum is exact
     for bits in (3, 12, 15):
@@ -943,7 +977,11 @@ def test_layernorm_bwd_bias_gradient_output(rows, C, rate, dtype):
     dbias = torch.full((C,), 0.5, device=DEV)
     dz, dy = ops.dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dg, db, rate, 77, dbias=dbias)
     dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    dz2, dy2 = ops.dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dg2, db2, rate, 77)
+    try:        # the same kernel family for both calls (without dbias a training shape would take ln_bwd_line: equal to rounding only)
+        ops.set_option('ln_prefetch', LN_DEFAULT & ~32)
+        dz2, dy2 = ops.dropout_add_layernorm_bwd(dout, z, gamma, mean, rstd, dg2, db2, rate, 77)
+    finally:
+        ops.set_option('ln_prefetch', LN_DEFAULT)
     assert torch.equal(dz, dz2) and torch.equal(dy, dy2)
     assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db, db2, rtol=1e-4, atol=1e-3)
     want = 0.5 + dy.double().sum(0)
