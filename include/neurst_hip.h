@@ -45,8 +45,11 @@ int neurst_abi_version(void);
  * "gemm256_bn" 0 / 192 / 256 = column width of its tiles (0: chosen per problem); "mha_fused" 0 / 1 / 2 = the wide
  * attention forward and the one-kernel backward of attention2.hip never / for encoder-size shapes / whenever they can
  * take the shape (bf16, dh = 96 or 64, no causal mask); "mha_small_fused" 1/0 = dQ and dK / dV of short-query shapes
- * (Tq <= 256) in one launch; "mha_bwd_waves" 4 / 8 = waves per workgroup of the one-kernel backward; "conv_fast" 1/0 = bf16 fast paths of the conv front end; "ln_prefetch" bits 1 / 2 = LayerNorm
- * forward / backward row loops request the next row ahead of the current row's stores.  Unknown names: NEURST_E_INVALID. */
+ * (Tq <= 256) in one launch; "mha_bwd_waves" 4 / 8 = waves per workgroup of the one-kernel backward; "conv_fast" 1/0 =
+ * bf16 fast paths of the conv front end; "ln_prefetch" bits (default 53): 16 / 32 = LayerNorm forward / backward of bf16 rows of
+ * 768, 512 or 256 columns without a row mask through the straight-line kernels, 1 / 2 = the general forward / backward row
+ * loops request the next row ahead of the current row's stores, 4 / 8 = they take 8-byte lanes where a row is whole wave
+ * passes of them.  Unknown names: NEURST_E_INVALID. */
 int neurst_set_option(const char* name, int value);
 
 /* a1: splice(left=0,right=num_context) + down_sample(rate)
