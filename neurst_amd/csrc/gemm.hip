@@ -25,10 +25,12 @@ __device__ __forceinline__ void mma_tile(const T* __restrict__ Ac, const T* __re
     for (int i = 0; i < MI; ++i) af[i] = SA::frag(Ac, wm * (16 * MI) + i * 16, ks, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[j] = SB::frag(Bc, wn * 64 + j * 16, ks, lane);
+    if constexpr (sizeof(T) == 2) __builtin_amdgcn_s_setprio(1);   // a wave with its fragments in registers issues its MFMAs ahead of its neighbours' loads
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+    if constexpr (sizeof(T) == 2) __builtin_amdgcn_s_setprio(0);
     // the sum rides on the fragments already in registers: one more MFMA per fragment against ones (duty) or
     // zeros (not duty) - branch-free, so the register allocation of the main loop is unchanged
     if constexpr (SUMOP == 1) {
