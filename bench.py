@@ -375,7 +375,16 @@ def main():
     # BASELINE config 3 rides along (rank 0 of a one-GPU run of the default LUT config): the COSTT step - d = 512, 6 + 6 + 6
     # blocks, shrink layer, SpecAugment, L = 80 - measured AFTER the LUT regions on the same GPU, same batch shape
     secondary = None
+    losses = out4.cpu().numpy()
+    T2_main = int(model.last['encoded'].shape[1])
     if world == 1 and is_lut and not a.no_secondary and os.path.basename(a.config) == 'lut.yaml':
+        # the LUT model is done: its arenas and activations go back to the allocator before the second model is built (with the
+        # first model alive the COSTT step - close to the host's launch rate - measured 9.8-10.2 ms here against 9.3 in a
+        # process of its own; freed first: 9.05-9.3)
+        import gc
+        del model, batch, out4
+        gc.collect()
+        torch.cuda.empty_cache()
         try:
             cargs = build_args(os.path.join(ROOT, 'configs', 'costt.yaml'), dim_output=V, compute_dtype=a.dtype)
             cmodel = cargs.Model(GlobalStep(1000), encoder=cargs.model.encoder.type, decoder=cargs.model.decoder.type, is_train=True, args=cargs)
@@ -408,14 +417,13 @@ def main():
             secondary = {'costt': {'error': repr(e)}}
     if use_dist:
         dist.barrier()
-    losses = out4.cpu().numpy()
     assert np.isfinite(losses).all(), losses
     step_s = dt / a.steps
     frames = B * T * world
 
     if rank == 0:
         d = args.model.encoder.num_cell_units
-        T2 = int(model.last['encoded'].shape[1]) if not is_lut else T      # COSTT: padded length after the shrink layer (data dependent)
+        T2 = T2_main if not is_lut else T      # COSTT: padded length after the shrink layer (data dependent)
         fwd, tot = lut_step_flops(B, T, Ln, 40, V, d=d, nenc=args.model.encoder.num_blocks, nenc2=args.model.encoder2.num_blocks,
                                   ndec=args.model.decoder.num_blocks, T2=T2, kd=is_lut)
         peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
