@@ -511,10 +511,12 @@ __global__ void __launch_bounds__(NT) gemm_persist_kernel(GemmArgs g) {
 // issues 64 MFMAs per K-step, so the K loop (12 - 156 steps) is a serial chain of ~0.45 us links.  32 x 128 tiles (wave
 // tile 16 x 64) put 240 workgroups on the chip with 16 MFMAs per wave and K-step.  Same 4-stage direct-to-LDS pipeline
 // as the small-grid path of gemm_kernel; A is K-contiguous (NT / NN).
-template <typename TC, bool TB_KCONTIG, bool SIMPLE>
+// BMT = 64 (wave tile 32 x 64): for grids of 65 - 128 tiles of 128 x 128 (2560 decoder rows at d = 512: 80 tiles -> 160 workgroups)
+template <typename TC, bool TB_KCONTIG, bool SIMPLE, int BMT = 32>
 __global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
   typedef bf16_t T;
-  constexpr int BK = 64, NS = 4, BMT = 32;
+  constexpr int BK = 64, NS = 4, MI = BMT / 32;
+  static_assert(BMT == 32 || BMT == 64, "row tiles of 32 or 64");
   typedef Stager<T, false, BK, BMT> SA;
   typedef Stager<T, !TB_KCONTIG, BK> SB;
   constexpr int STAGE_BYTES = NS * (SA::TILE + SB::TILE) * (int)sizeof(T);
@@ -530,9 +532,11 @@ __global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
   const int64_t m0 = (int64_t)tm * BMT, n0 = (int64_t)tn * BN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
-  f32x4 acc[1][4], sacc[4];
+  f32x4 acc[MI][4], sacc[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bcol[4] = {0.f, 0.f, 0.f, 0.f};
   if (g.bias) {
 #pragma unroll
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
       issue_glds<T, false, BK, BMT>(A, g.lda, m0, kn, g.M, As(nb), tid);
       issue_glds<T, !TB_KCONTIG, BK>(B, g.ldb, n0, kn, g.N, Bs(nb), tid);
     }
-    mma_tile<T, SA, SB, 0, 1>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
+    mma_tile<T, SA, SB, 0, MI>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
     cur = (cur + 1) % NS;
   }
   const int64_t ktail = (int64_t)nfull * BK;
@@ -578,26 +582,37 @@ __global__ void __launch_bounds__(NT) gemm_thin_kernel(GemmArgs g) {
     sa.store(As(cur), tid);
     sb.store(Bs(cur), tid);
     __syncthreads();
-    mma_tile<T, SA, SB, 0, 1>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
+    mma_tile<T, SA, SB, 0, MI>(As(cur), Bs(cur), acc, sacc, false, wm, wn, lane);
   }
-  persist_epilogue<T, TC, 1, SIMPLE>(g, acc, bcol, Cs, m0 + wm * 16, n0 + wn * 64, lane);
+  persist_epilogue<T, TC, MI, SIMPLE>(g, acc, bcol, Cs, m0 + wm * (16 * MI), n0 + wn * 64, lane);
 }
 
 static int thin_max_tiles() {
   static const int v = [] { const char* e = getenv("NEURST_GEMM_THIN_MAX_TILES"); return e ? atoi(e) : 64; }();
   return v;
 }
-// true if the launch was taken by the thin-tile kernel: K-contiguous A, at most thin_max_tiles() tiles of 128 x 128
+static int thin64_max_tiles() {
+  static const int v = [] { const char* e = getenv("NEURST_GEMM_THIN64_MAX_TILES"); return e ? atoi(e) : 128; }();
+  return v;
+}
+// true if the launch was taken by a thin-tile kernel: K-contiguous A, at most thin_max_tiles() tiles of 128 x 128 (row tiles of
+// 32) or thin64_max_tiles() of them (row tiles of 64)
+template <typename TC, int BMT>
+static void launch_thin_bmt(const GemmArgs& g, int trans_b, hipStream_t s) {
+  GemmArgs t = g;
+  t.tiles_m = (int)cdiv64(g.M, BMT);
+  const int grid = t.tiles_m * t.tiles_n;
+  const bool simple = !g.relu_src && !g.accumulate && g.c_vec && g.N % 8 == 0;
+  if (trans_b) { if (simple) gemm_thin_kernel<TC, true, true, BMT><<<grid, NT, 0, s>>>(t); else gemm_thin_kernel<TC, true, false, BMT><<<grid, NT, 0, s>>>(t); }
+  else { if (simple) gemm_thin_kernel<TC, false, true, BMT><<<grid, NT, 0, s>>>(t); else gemm_thin_kernel<TC, false, false, BMT><<<grid, NT, 0, s>>>(t); }
+}
 template <typename TC>
 static bool launch_gemm_thin(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
   if (trans_a || g.split_k != 1 || g.K < 256) return false;
-  if ((int64_t)g.tiles_m * g.tiles_n > thin_max_tiles()) return false;
-  GemmArgs t = g;
-  t.tiles_m = (int)cdiv64(g.M, 32);
-  const int grid = t.tiles_m * t.tiles_n;
-  const bool simple = !g.relu_src && !g.accumulate && g.c_vec && g.N % 8 == 0;
-  if (trans_b) { if (simple) gemm_thin_kernel<TC, true, true><<<grid, NT, 0, s>>>(t); else gemm_thin_kernel<TC, true, false><<<grid, NT, 0, s>>>(t); }
-  else { if (simple) gemm_thin_kernel<TC, false, true><<<grid, NT, 0, s>>>(t); else gemm_thin_kernel<TC, false, false><<<grid, NT, 0, s>>>(t); }
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
+  if (tiles <= thin_max_tiles()) launch_thin_bmt<TC, 32>(g, trans_b, s);
+  else if (tiles <= thin64_max_tiles()) launch_thin_bmt<TC, 64>(g, trans_b, s);
+  else return false;
   return true;
 }
 

@@ -184,7 +184,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, bias=None, relu=Fals
     return C
 
 
-THIN_MAX_TILES = int(os.environ.get('NEURST_GEMM_THIN_MAX_TILES', '64'))         # csrc/gemm.hip: thin_max_tiles()
+THIN_MAX_TILES = max(int(os.environ.get('NEURST_GEMM_THIN_MAX_TILES', '64')),    # csrc/gemm.hip: thin_max_tiles() (32-row tiles)
+                     int(os.environ.get('NEURST_GEMM_THIN64_MAX_TILES', '128')))  # and thin64_max_tiles() (64-row tiles)
 PERSIST_MIN_TILES = int(os.environ.get('NEURST_GEMM_PERSIST_MIN_TILES', '1024'))   # csrc/gemm.hip: persist_min_tiles()
 
 

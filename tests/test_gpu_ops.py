@@ -113,10 +113,12 @@ def test_gemm_persistent_many_tiles(ta, tb, M, N, K, cdt):
 
 @pytest.mark.parametrize('tb', [1, 0])
 @pytest.mark.parametrize('M,N,K,cdt', [(1280, 768, 768, 'bf16'), (1280, 768, 3072, 'bf16'), (70, 136, 256, 'bf16'), (333, 520, 640, 'f32'),
-                                       (1280, 768, 10000, 'bf16'), (96, 128, 8 * 37, 'f32')])
+                                       (1280, 768, 10000, 'bf16'), (96, 128, 8 * 37, 'f32'),
+                                       (2560, 512, 512, 'bf16'), (1700, 1000, 8 * 41, 'bf16'), (2560, 768, 2048, 'f32')])   # 80 / 112 / 120 tiles: 64-row tiles
 def test_gemm_thin_tiles(tb, M, N, K, cdt):
     """aligned bf16 problems with K-contiguous A and at most 64 tiles of 128 x 128 take the 32 x 128-tile
-    kernel: ragged edges, a partial last K-tile, bias + relu, accumulate and the relu-gradient gate."""
+    kernel, up to 128 tiles the 64 x 128-tile one: ragged edges, a partial last K-tile, bias + relu, accumulate and the
+    relu-gradient gate."""
     rng = np.random.default_rng(M + K + tb)
     A = bf16_round(rng.standard_normal((M, K)))
     B = bf16_round(rng.standard_normal((N, K) if tb else (K, N)))

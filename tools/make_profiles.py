@@ -37,7 +37,7 @@ def gemm_label(name):
     if mp:
         lay = {('false', 'true'): 'NT', ('false', 'false'): 'NN', ('true', 'false'): 'TN'}[mp.groups()[1:]]
         return 'gemm_persist_kernel<bf16,%s,%s>' % ('f32' if mp.group(1) == 'float' else 'bf16', lay)
-    mt = re.match(r'_Z16gemm_thin_kernelI(DF16b|f)Lb([01])E(?:Lb[01]E)?Ev8GemmArgs', name)
+    mt = re.match(r'_Z16gemm_thin_kernelI(DF16b|f)Lb([01])E(?:Lb[01]E)?(?:Li\d+E)?Ev8GemmArgs', name)
     if mt:
         return 'gemm_thin_kernel<bf16,%s,%s>' % ('bf16' if mt.group(1) == 'DF16b' else 'f32', 'NT' if mt.group(2) == '1' else 'NN')
     mt = re.match(r'void gemm_thin_kernel<(float|bool _Accum|__bf16), (true|false|bool)', name)   # rocprofv3's half-demangled spellings
