@@ -42,7 +42,8 @@ int neurst_abi_version(void);
 /* Kernel-selection switches for tests and A/B timing (no reference counterpart; defaults come from the environment
  * variables of the same upper-case name with the NEURST_ prefix): "gemm256" 1/0 = large bf16 GEMMs may use the
  * 256 x 256-tile kernel; "gemm256_min_tiles" = smallest number of 256 x 256 tiles for which it is chosen (128);
- * "gemm256_bn" 0 / 192 / 256 = column width of its tiles (0: chosen per problem); "mha_fused" 0 / 1 / 2 = the wide
+ * "gemm256_bn" 0 / 192 / 256 = column width of its tiles (0: chosen per problem); "gemm256_max_grid" n >= 8 = its persistent
+ * launches use at most n workgroups (a launch beside a latency-bound chain on another stream leaves that chain CUs), 0 = all; "mha_fused" 0 / 1 / 2 = the wide
  * attention forward and the one-kernel backward of attention2.hip never / for encoder-size shapes / whenever they can
  * take the shape (bf16, dh = 96 or 64, no causal mask); "mha_small_fused" 1/0 = dQ and dK / dV of short-query shapes
  * (Tq <= 256) in one launch; "mha_bwd_waves" 4 / 8 = waves per workgroup of the one-kernel backward; "conv_fast" 1/0 =

@@ -678,6 +678,7 @@ static int launch_gemm(const GemmArgs& g, int trans_a, int trans_b, hipStream_t 
 static int g_opt_gemm256 = [] { const char* e = getenv("NEURST_GEMM256"); return e ? atoi(e) : 1; }();
 int g_opt_gemm256_bn = 0;
 int g_opt_gemm256_ablate = 0;
+int g_opt_gemm256_max_grid = 0;
 int g_opt_gemm256_min_tiles = [] { const char* e = getenv("NEURST_GEMM256_MIN_TILES"); return e ? atoi(e) : 128; }();
 static bool use_gemm256() { return g_opt_gemm256 != 0; }
 int neurst_attention2_set_option(const char* name, int value);
@@ -689,6 +690,7 @@ extern "C" int neurst_set_option(const char* name, int value) {
   else if (!strcmp(name, "gemm256_min_tiles")) g_opt_gemm256_min_tiles = value;
   else if (!strcmp(name, "gemm256_bn")) g_opt_gemm256_bn = value;
   else if (!strcmp(name, "gemm256_ablate")) g_opt_gemm256_ablate = value;
+  else if (!strcmp(name, "gemm256_max_grid")) g_opt_gemm256_max_grid = value;
   else if (!strcmp(name, "conv_fast")) g_opt_conv_fast = value;
   else if (!strcmp(name, "ln_prefetch")) g_opt_ln_prefetch = value;
   else if (neurst_attention2_set_option(name, value)) {}

@@ -561,6 +561,7 @@ __global__ void __launch_bounds__(NT, 2) gemm256_group_kernel(GroupArgs ga) {
 // addressed by 32-bit byte offsets from a tile origin.  trans_a: A stored [K][M]; trans_b: B stored [N][K].
 extern int g_opt_gemm256_min_tiles;                          // gemm.hip: neurst_set_option("gemm256_min_tiles", n)
 extern int g_opt_gemm256_ablate;
+extern int g_opt_gemm256_max_grid;
 extern int g_opt_gemm256_bn;                                 // 0 = choose per problem, 192 / 256 = forced
 static int t2_min_tiles() { return g_opt_gemm256_min_tiles; }
 // Column width of the output tile: 256 or 192.  Cost model (measured, tools/exp/gemm256_driver): a round of 256-wide tiles
@@ -616,6 +617,7 @@ static void launch256(const GemmArgs& g0, int trans_a, int trans_b, hipStream_t 
   a.ablate = g_opt_gemm256_ablate;
   const int ntiles = a.g.tiles_m * a.g.tiles_n;
   int grid = ntiles >= 256 ? 256 : (ntiles + 7) / 8 * 8;
+  if (g_opt_gemm256_max_grid >= 8 && grid > g_opt_gemm256_max_grid) grid = g_opt_gemm256_max_grid / 8 * 8;   // experiment: leave CUs to another stream
   if constexpr (sizeof(TC) == 2) {
     if (g_stamps && !trans_a && trans_b) { t2::gemm256_kernel<TC, false, true, NI1, true><<<grid, t2::NT, 0, s>>>(a); return; }
     if constexpr (NI1 == 2) {

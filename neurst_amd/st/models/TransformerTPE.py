@@ -277,7 +277,13 @@ class TransformerTPE(Seq2SeqModel):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 with G.variable_scope(self.decoder.name or 'decoder'):
-                    logits_am, _, len_logits_am = self.decoder_ctc(encoded=encoded_am, len_encoded=len_encoded_am)
+                    if g.side_gemm_grid:            # see graph.py: the head GEMM leaves CUs to the decoder's chain
+                        ops.set_option('gemm256_max_grid', g.side_gemm_grid)
+                    try:
+                        logits_am, _, len_logits_am = self.decoder_ctc(encoded=encoded_am, len_encoded=len_encoded_am)
+                    finally:
+                        if g.side_gemm_grid:
+                            ops.set_option('gemm256_max_grid', 0)
                 if g.dtype == ops.F32 and self.keep_logits:
                     self.last['logits_am'] = logits_am.clone()      # the fp32 gradient overwrites the logits in place
                 loss_ctc, argmax_am = self.ctc_loss(logits=logits_am, len_logits=len_logits_am, labels=batch['aux_label'],

@@ -255,6 +255,11 @@ class Graph:
         self.side_reads = set()
         self.side_keep = []
         self.side_used = False
+        # The CTC head's chip-wide persistent GEMMs (forward on the CTC stream, data gradient as an early node) run beside the
+        # decoder's chain of small launches: with one workgroup on every CU they leave that chain nothing until a tile ends;
+        # launched on this many CUs they take longer themselves (they have the slack) and the chain keeps moving.
+        # Measured: 128 -> 12.51 against 12.56 ms per step, 160 12.52, 96 and 64 slower (12.62-12.65); 0 = the whole chip.
+        self.side_gemm_grid = int(os.environ.get('NEURST_SIDE_GRID', '128'))
         self.in_early = False
         self.early_stream = None     # stream for early backward nodes (default: the weight-gradient stream)
         self.early_used = set()
@@ -376,10 +381,15 @@ class Graph:
             # soon as the loss kernels before it are done
             self.early_used.add(side)
         self.in_early = True
+        grid = self.side_gemm_grid if self.early_stream is not None else 0    # only beside the decoder's chain (deferred CTC branch)
         try:
+            if grid:
+                ops.set_option('gemm256_max_grid', grid)
             with torch.cuda.stream(side):
                 fn()
         finally:
+            if grid:
+                ops.set_option('gemm256_max_grid', 0)
             self.in_early = False
         self.side_used = True
         return True
