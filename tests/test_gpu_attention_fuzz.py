@@ -1,0 +1,96 @@
+"""-m gpu: seeded random walk over the attention dispatcher (csrc/attention.hip tiled / short-query kernels,
+csrc/attention2.hip fused forward and backward) through the C ABI, against the fp64 oracle (oracle/ops.py mha_core_*,
+a restatement of multihead_attention + dot_product_attention, /root/reference/st/layers/common_attention_v1.py:325-365).
+
+The fixed cases of test_gpu_ops.py pin one shape per kernel; here head width, lengths on both sides of every dispatch
+threshold (Tq 128 / 256, Tk 128, key blocks of 128 / 256), mask mode, ragged key lengths, dropout and the way its decisions
+travel (hashed again or stored bits) are drawn independently.  Tolerances as in the fixed cases: fp32 2e-5, bf16 3e-2 of the
+tensor's maximum."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from neurst_amd import ops
+    DEV = torch.device('cuda:0')
+
+
+def _bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def _relerr(a, b):
+    # a gradient that is exactly zero (Tk = 1: the softmax of one key is constant) is compared on the unit scale of the inputs:
+    # what the kernels leave there is the rounding of O and dO in delta = rowsum(dO * O), not a fraction of the result
+    den = np.abs(b).max()
+    return np.abs(a - b).max() / (den if den > 1e-6 else 1.0)
+
+
+LENGTHS = [1, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 530]
+
+
+def _check(rng, seed, dtype, dh, mode, Tq, Tk, B, H, rate, stored):
+    d = H * dh
+    td, tol = (torch.bfloat16, 3e-2) if dtype == 'bf16' else (torch.float32, 2e-5)
+    q, k, v, do = (rng.standard_normal((B, T, d)).astype(np.float32) * 0.7 for T in (Tq, Tk, Tk, Tq))
+    if dtype == 'bf16':
+        q, k, v, do = _bf16(q), _bf16(k), _bf16(v), _bf16(do)
+    lens = rng.integers(1, Tk + 1, size=B).astype(np.int32)
+    lens[0] = Tk
+    mm = {'none': O.MASK_NONE, 'keypad': O.MASK_KEYPAD, 'causal': O.MASK_CAUSAL}[mode]
+    key = O.site_key(3, 17 + seed, 1)
+    what = dict(seed=seed, dtype=dtype, B=B, H=H, Tq=Tq, Tk=Tk, dh=dh, mode=mode, rate=rate, stored=stored, lens=lens.tolist())
+    ref, cache = O.mha_core_fwd(q.astype(np.float64), k.astype(np.float64), v.astype(np.float64), H, mm, lens, rate, key)
+    dq_r, dk_r, dv_r = O.mha_core_bwd(do.astype(np.float64), cache)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(td)
+    qd, kd, vd, dod = to(q), to(k), to(v), to(do)
+    ld = torch.from_numpy(lens).to(DEV) if mode == 'keypad' else None
+    kb = None
+    if stored:
+        o, lse, kb = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=True)
+    else:
+        o, lse = ops.mha_fwd(qd, kd, vd, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key)
+    assert _relerr(o.float().cpu().numpy(), ref) < tol, ('o', what)
+    dq, dk, dv = (torch.full_like(x, float('nan')) for x in (qd, kd, vd))
+    ops.mha_bwd(qd, kd, vd, o, dod, lse, dq, dk, dv, d, d, d, d, d, d, B, H, Tq, Tk, dh, mm, ld, rate, key, keep_bits=kb)
+    for name, got, want in (('dq', dq, dq_r), ('dk', dk, dk_r), ('dv', dv, dv_r)):
+        g = got.float().cpu().numpy()
+        assert np.isfinite(g).all(), (name, what)
+        assert _relerr(g, want) < tol, (name, _relerr(g, want), what)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_attention_random_shapes(seed):
+    """every head width, mask mode and dtype; mostly a handful of (batch, head) pairs: the tiled and short-query kernels"""
+    rng = np.random.default_rng(40503 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    dtype = 'bf16' if seed % 4 else 'f32'
+    dh = pick([96, 64, 96, 64, 32, 128, 192, 8]) if dtype == 'bf16' else pick([96, 64, 32, 16])
+    mode = pick(['keypad', 'keypad', 'none', 'causal'])
+    Tq = pick(LENGTHS)
+    Tk = Tq if mode == 'causal' or rng.integers(0, 2) else pick(LENGTHS)
+    B, H = (pick([16, 22]), 8) if seed % 3 == 0 and Tq * Tk <= 300 * 300 else (int(rng.integers(1, 4)), int(rng.integers(1, 5)))
+    rate = pick([0.0, 0.1, 0.1, 0.3])
+    stored = rate > 0 and bool(rng.integers(0, 2))
+    _check(rng, seed, dtype, dh, mode, Tq, Tk, B, H, rate, stored)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_attention_random_shapes_on_the_fused_kernels(seed):
+    """what training launches: bf16, head width 96 or 64, at least 128 (batch, head) pairs and 128 keys, decisions stored -
+    the one-kernel backward of attention2.hip (any Tq) and its forward (Tq >= 128); B * H not a multiple of 8 in a third"""
+    rng = np.random.default_rng(90001 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    dh = 96 if seed % 2 else 64
+    mode = pick(['keypad', 'keypad', 'none'])
+    Tq = pick(LENGTHS)
+    Tk = pick([t for t in LENGTHS if t >= 128])
+    B, H = pick([16, 17, 22]), 8
+    if B == 17:
+        H = 9                                  # 153 pairs: the XCD-contiguous order with a remainder
+    rate = pick([0.0, 0.1, 0.3])
+    _check(rng, seed, 'bf16', dh, mode, Tq, Tk, B, H, rate, rate > 0)
