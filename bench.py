@@ -391,8 +391,11 @@ def main():
             chost = make_batch(B=B, Traw=Traw, V=V, L=80, U=40, Lb=40, bert_dim=None, seed=1234, ragged=a.ragged)
             cbatch = {k: torch.from_numpy(v).cuda() for k, v in chost.items()}
             # warm-up in two legs: the first steps run at the full length (the shrink layer's bound is learnt from finished
-            # steps), the next ones at the learnt bound (new buffer shapes for the allocator); only then the timed steps
-            for leg in (2, 6):
+            # steps), the next ones at the learnt bound (new buffer shapes for the allocator); only then the timed steps.
+            # Twelve steps in all: the bound is 1.25 x the maximum over the last EIGHT settled steps, and the first step of a
+            # freshly initialised model keeps nearly every frame (478 of 500), so until that step has left the history the
+            # shrunk tensor is sized for the full length (12.4 instead of 8.6 ms per step)
+            for leg in (2, 10):
                 for _ in range(leg):
                     cmodel.train_step_async(cbatch)
                 torch.cuda.synchronize()

@@ -3,6 +3,7 @@ blank, differs from the previous frame's and t < len; gather the kept rows per u
 to max(max count, 1).  The reference's serial tf.while_loop with growing concat is replaced by one
 prefix-count kernel and one gather kernel; one [B] int32 read-back sizes the output like the reference."""
 import collections
+import os
 
 import torch
 
@@ -28,13 +29,16 @@ class ShrinkSpeculation:
         self.free = []                         # pinned host buffers of settled steps
         self.force_full = False
         self.last = None
+        # measurement aid: never size the shrunk tensor below this many frames (what a step costs when about that many frames
+        # are kept: a synthetic batch trains to all-blank CTC output - one kept frame - within a few steps)
+        self.min_bound = int(os.environ.get('NEURST_SHRINK_MIN_BOUND', '0'))
 
     def next_bound(self, T):
         if self.force_full or not self.history:
             return int(T)
         b = int(self.margin * max(self.history)) + self.slack
         b = -(-b // self.quantum) * self.quantum
-        return max(1, min(int(T), b))
+        return max(1, min(int(T), max(b, self.min_bound)))
 
     def clamp(self, len_labels, T):
         """enqueue: clamp the lengths to the bound of this step, copy (flag, max) to pinned memory, remember the event"""

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""ms per step in consecutive chunks of 10 steps from a cold start (how long is the transient the bench's warm-up must cover?)
+usage: step_series.py configs/costt.yaml|configs/lut.yaml [chunks]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from neurst_amd.st.layers.arguments import build_args  # noqa: E402
+from neurst_amd.st.models.TransformerTPE import GlobalStep  # noqa: E402
+from neurst_amd.synthetic import make_batch  # noqa: E402
+
+cfg = sys.argv[1]
+chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+torch.cuda.set_device(0)
+args = build_args(os.path.join(ROOT, cfg), dim_output=10000, compute_dtype='bf16')
+is_lut = args.model.loss_type == 'ctc_kd_ce'
+model = args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
+host = make_batch(B=32, Traw=1500, V=10000, L=40 if is_lut else 80, U=40, Lb=40, bert_dim=768 if is_lut else None, seed=1234)
+batch = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+out = []
+if os.environ.get('FREEZE') == 'build':
+    import gc
+    gc.collect()
+    gc.freeze()
+for c in range(chunks):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        model.train_step_async(batch)
+    torch.cuda.synchronize()
+    out.append((time.perf_counter() - t0) * 100)
+    if c == 0 and os.environ.get('FREEZE') == 'warm':
+        import gc
+        gc.collect()
+        gc.freeze()
+    spec = getattr(model.graph, 'shrink_spec', None)
+    if spec is not None and c < 3:
+        print('chunk', c, 'bound history', list(spec.history), flush=True)
+print(cfg, ' '.join('%.2f' % v for v in out), flush=True)
