@@ -19,7 +19,7 @@ torch.cuda.set_device(0)
 args = build_args(os.path.join(ROOT, cfg), dim_output=10000, compute_dtype='bf16')
 is_lut = args.model.loss_type == 'ctc_kd_ce'
 model = args.Model(GlobalStep(1000), encoder=args.model.encoder.type, decoder=args.model.decoder.type, is_train=True, args=args)
-host = make_batch(B=32, Traw=1500, V=10000, L=40 if is_lut else 80, U=40, Lb=40, bert_dim=768 if is_lut else None, seed=1234)
+host = make_batch(B=int(os.environ.get('B', '32')), Traw=1500, V=10000, L=40 if is_lut else 80, U=40, Lb=40, bert_dim=768 if is_lut else None, seed=1234)
 batch = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
 out = []
 if os.environ.get('FREEZE') == 'build':
