@@ -19,6 +19,8 @@
 // one pass and no scratch traffic.  dQ of slice i - 1 is computed in iteration i, beside the vector work of slice i, so the
 // loop needs ONE barrier per slice.  Q / dO slices and the K image arrive by LDS-DMA (buffer_load ... lds) with the
 // bank swizzle applied on the source side; rows beyond the tensor read as zeros through the descriptor's range.
+#include <algorithm>
+
 #include "attention2.h"
 
 #define NEG_BIAS (-1e9f)
@@ -35,7 +37,9 @@ struct Args {
   bf16_t *dq, *dk, *dv;
   const float* lse;
   float* delta;
-  float* ws;                 // [B*H][Tq][DH] fp32 partial dQ (only touched when Tk needs more than one key block)
+  float* ws;                 // [ksplit][B*H][Tq][DH] fp32 partial dQ (only touched when Tk needs more than one key block)
+  int64_t ws_part;           // floats per part of ws
+  int ksplit;                // workgroups per (batch, head): part p takes key blocks p, p + ksplit, ...
   const uint32_t* keep;      // row-major keep bitmap (attention.hip), or null when rate == 0
   const int32_t* len_k;
   int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
@@ -120,7 +124,7 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, g = lane >> 5;
   const int G = lane >> 4, qq = (lane & 15) >> 2, p4 = lane & 3;
-  const int bh = xcd_run((int)blockIdx.x, (int)gridDim.x), b = bh / a.H, h = bh % a.H;
+  const int vid = xcd_run((int)blockIdx.x, (int)gridDim.x), bh = vid / a.ksplit, part = vid - bh * a.ksplit, b = bh / a.H, h = bh % a.H;
   const int Tq = a.Tq, Tk = a.Tk;
   const int nslice = (Tq + QS - 1) / QS, tqp = nslice * QS;
   float* lse2_s = reinterpret_cast<float*>(smem + L::STAT0);
@@ -138,6 +142,12 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
   const int len = a.keypad ? a.len_k[b] : Tk;
   const int kv_end = (a.keypad && len > 0 && len < Tk) ? len : Tk;      // keys at and beyond it get exactly zero weight
   const int nkb = (kv_end + KB - 1) / KB;
+  // Key blocks over several workgroups (fewer (batch, head) pairs than CUs: batch 16 at eight heads).  Part p sweeps the blocks
+  // p, p + ksplit, ... and leaves its dQ as fp32 partial sums in its own slice of the workspace; mha2_dq_reduce_kernel, launched
+  // behind this kernel, adds the slices up and writes dQ.  A part without a block (short utterance) has nothing to do.
+  const int nparts = nkb < a.ksplit ? nkb : a.ksplit;                    // parts of this pair that own a key block
+  if (part >= nparts) return;                                             // (workgroup-uniform, before any barrier or DMA)
+  float* const wsq = a.ws + (int64_t)part * a.ws_part;
   int n_stamp = 0;
   auto stamp = [&]() __attribute__((always_inline)) {
     if constexpr (STAMPS) {
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
     }
   };
   // the first block's K image and query slice are on their way while the statistics below are computed
-  issue_kimage(0);
+  issue_kimage(part);
   issue_slice(0);
 
   // ---- statistics of every query: lse2 = lse * log2(e) (+inf beyond Tq: p = 0), delta = rowsum(dO * O).  Four lanes per
@@ -264,9 +274,9 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
     }
   }
 
-  for (int kb = 0; kb < nkb; ++kb) {
+  for (int kb = part; kb < nkb; kb += a.ksplit) {
     const int K0 = kb * KB;
-    if (kb > 0) {
+    if (kb != part) {
       __syncthreads();                                                    // previous pass has left the K image and the staging buffers
       issue_kimage(kb);
       issue_slice(0);
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) { dk[blk][db][v] = 0.f; dv[blk][db][v] = 0.f; }
     uint32_t kw_next = load_kw(0, kb);
-    const bool first = kb == 0, last = kb == nkb - 1;
+    const bool first = kb == part, last = kb + a.ksplit >= nkb && nparts == 1;   // last: dQ is complete in this pass
 
     // dQ of slice sl from dsT[sl & 1] and the K image, in KB / 32 k-steps that the slice loop places between the groups of
     // its vector work; added to / stored over the partial sums (workspace rows padded to whole slices)
@@ -320,7 +330,7 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const int q_base = sl * QS + 16 * dq_qh + 4 * (ln >> 4);           // + r: the four queries of this lane's accumulator registers
-      const float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (ln & 15);
+      const float* wsp = wsq + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (ln & 15);
 #pragma unroll
       for (int n = 0; n < NT; ++n)
         if (n < ntw) {
@@ -365,7 +375,7 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
             }
         }
       } else {
-        float* wsp = a.ws + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (ln & 15);
+        float* wsp = wsq + ((int64_t)bh * tqp + q_base) * DH + dq_d0 + (ln & 15);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           if (n < ntw) {
@@ -537,7 +547,7 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
   }
   stamp();
   // ---- keys the passes did not visit (behind the valid length): exactly zero gradients
-  {
+  if (part == 0) {
     const bf16x8 zero = {};
     const int k_first = nkb * KB;
     for (int n = tid; n < (Tk - k_first) * CH; n += NTHR) {
@@ -545,6 +555,33 @@ __global__ void __launch_bounds__(NW * 64) mha2_bwd_kernel(Args a) {
       *reinterpret_cast<bf16x8*>(a.dk + ((int64_t)b * Tk + key) * a.lddk + h * DH + ch * 8) = zero;
       *reinterpret_cast<bf16x8*>(a.dv + ((int64_t)b * Tk + key) * a.lddv + h * DH + ch * 8) = zero;
     }
+  }
+}
+
+// dQ of pairs whose key blocks went to several workgroups (a.ksplit > 1): bf16(qscale x the sum of the parts' fp32 slices), as a
+// launch of its own behind the backward kernel.  (First version: the part of a pair that finished last - an arrival counter per
+// pair behind __threadfence() - summed them inside the kernel.  Measured slower than no split at all, batch 16: 8.78 -> 8.83 ms
+// per step against 8.64 with the forward split alone; a device-scope release on this chip writes the XCD's L2 back, from every
+// wave of every workgroup, and one workgroup then walks 384 KB alone.  A kernel boundary orders the same data for free and
+// puts the whole chip on the sum.)
+template <int DH>
+__global__ void __launch_bounds__(256) mha2_dq_reduce_kernel(Args a) {
+  constexpr int C4 = DH / 4;
+  const int tqp = (a.Tq + QS - 1) / QS * QS;
+  const int64_t total = (int64_t)a.B * a.H * a.Tq * C4;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < total; n += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(n % C4);
+    const int64_t row = n / C4;                                           // (pair, query)
+    const int q = (int)(row % a.Tq), bh = (int)(row / a.Tq), b = bh / a.H, h = bh - b * a.H;
+    const int len = a.keypad ? a.len_k[b] : a.Tk;
+    const int kv_end = (a.keypad && len > 0 && len < a.Tk) ? len : a.Tk;
+    const int nkb = (kv_end + KB - 1) / KB, nparts = nkb < a.ksplit ? nkb : a.ksplit;
+    if (nparts == 1) continue;                                            // one part: its kernel wrote dQ itself
+    const float* src = a.ws + ((int64_t)bh * tqp + q) * DH + 4 * c4;
+    f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+    for (int pp = 1; pp < nparts; ++pp) sum += *reinterpret_cast<const f32x4*>(src + (int64_t)pp * a.ws_part);
+    const bf16x4 o4 = {(bf16_t)(sum[0] * a.qscale), (bf16_t)(sum[1] * a.qscale), (bf16_t)(sum[2] * a.qscale), (bf16_t)(sum[3] * a.qscale)};
+    *reinterpret_cast<bf16x4*>(a.dq + ((int64_t)b * a.Tq + q) * a.lddq + h * DH + 4 * c4) = o4;
   }
 }
 
@@ -597,6 +634,7 @@ struct FwdArgs {
   const int32_t* len_k;
   int64_t ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso;
   int B, H, Tq, Tk, nw, keypad, idx32;
+  int qsplit;                // workgroups per (batch, head): workgroup part p takes the groups of eight query slices p, p + qsplit, ...
   uint32_t key, inner0, t16;
   float qscale, keep_scale;
 };
@@ -611,7 +649,8 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, g = lane >> 5;
   const int G = lane >> 4, qq = (lane & 15) >> 2, p4 = lane & 3;
-  const int bh = xcd_run((int)blockIdx.x, (int)gridDim.x), b = bh / a.H, h = bh % a.H;
+  // (the parts of one (batch, head) are neighbours in the XCD's run: they read the same K / V rows through one L2)
+  const int vid = xcd_run((int)blockIdx.x, (int)gridDim.x), bh = vid / a.qsplit, part = vid - bh * a.qsplit, b = bh / a.H, h = bh % a.H;
   const int Tq = a.Tq, Tk = a.Tk;
   typedef __attribute__((address_space(3))) char* lds_cp;
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_cp)smem;
@@ -660,10 +699,10 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
       kwn[pr] = (ok && wi < a.nw) ? a.keep[rg * a.nw + wi] : 0u;
     }
   };
-  if constexpr (DROP && READY) load_kw(0, 0);
+  if constexpr (DROP && READY) load_kw(part, 0);
   issue_block(0, 0);
   int it = 0;                                                             // blocks consumed so far (buffer = it & 1)
-  for (int grp = 0; grp < ngroup; ++grp) {
+  for (int grp = part; grp < ngroup; grp += a.qsplit) {
     const int sl = grp * FW + w;                                          // this wave's slice (may lie beyond the last one: computes on zeros)
     const int q = sl * QS + c;
     const bool q_ok = q < Tq;
@@ -690,10 +729,10 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
       uint32_t kwc0 = kwn[0], kwc1 = kwn[1];                              // this block's stored keep words (landed: waited for above)
       {
         const int nkb_next = kb + 1 < nkb ? kb + 1 : 0;
-        const bool more = kb + 1 < nkb || grp + 1 < ngroup;
+        const bool more = kb + 1 < nkb || grp + a.qsplit < ngroup;
         if constexpr (DROP) {
           asm volatile("" : "+v"(kwc0), "+v"(kwc1));                      // their use stays in front of the next loads and DMA pieces
-          if (READY && more) load_kw(kb + 1 < nkb ? grp : grp + 1, nkb_next);
+          if (READY && more) load_kw(kb + 1 < nkb ? grp : grp + a.qsplit, nkb_next);
         }
         if (more) issue_block(nkb_next, (it + 1) & 1);
       }
@@ -852,9 +891,11 @@ __global__ void __launch_bounds__(512, 1) mha2_fwd_kernel(FwdArgs a) {
 static int g_opt_mha_bwd_waves = [] { const char* e = getenv("NEURST_MHA_BWD_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
 static int g_opt_fwd_ablate = 0;          // diagnostic: timing-only ablations of the wide forward (wrong results)
 extern int g_opt_mha_small_fused;         // attention.hip
+static int g_opt_mha_split = [] { const char* e = getenv("NEURST_MHA_SPLIT"); return e ? atoi(e) : 3; }();           // bit 1: forward, bit 2: backward; 0: one workgroup per (batch, head) whatever their number
 static int g_opt_mha_fused = [] { const char* e = getenv("NEURST_MHA_FUSED"); return e ? atoi(e) : 1; }();           // 0: never, 1: encoder-size shapes, 2: whenever the kernel can take the shape
 int neurst_attention2_set_option(const char* name, int value) {
   if (!strcmp(name, "mha_fused")) { g_opt_mha_fused = value; return 1; }
+  if (!strcmp(name, "mha_split")) { g_opt_mha_split = value; return 1; }
   if (!strcmp(name, "mha_small_fused")) { g_opt_mha_small_fused = value; return 1; }
   if (!strcmp(name, "mha_fwd_ablate")) { g_opt_fwd_ablate = value; return 1; }
   if (!strcmp(name, "mha_bwd_waves")) { if (value != 4 && value != 8) return 0; g_opt_mha_bwd_waves = value; return 1; }
@@ -862,8 +903,18 @@ int neurst_attention2_set_option(const char* name, int value) {
 }
 
 
+// workgroups per (batch, head) of the fused backward: the key blocks of a pair go to several workgroups when there are fewer
+// pairs than CUs (NEURST_MHA_SPLIT=0 / neurst_set_option("mha_split", 0): always one)
+static int64_t bwd_ksplit(int64_t B, int64_t H, int64_t Tk) {
+  const int64_t nkb = cdiv64(Tk, a2::KB), per_chip = (g_opt_mha_split & 2) ? 256 / (B * H) : 1;
+  return per_chip < 1 ? 1 : (per_chip > nkb ? nkb : per_chip);
+}
+static int64_t bwd_ws_part_floats(int64_t B, int64_t H, int64_t Tq, int64_t dh) { return B * H * cdiv64(Tq, a2::QS) * a2::QS * dh; }   // query rows padded to whole slices
 extern "C" int64_t neurst_mha_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t dh) {
-  return Tk > a2::KB ? B * H * cdiv64(Tq, a2::QS) * a2::QS * dh * (int64_t)sizeof(float) : 0;   // query rows padded to whole slices
+  if (Tk <= a2::KB) return 0;
+  // fp32 partial dQ per part (the largest split any option setting can ask for)
+  const int64_t parts = std::max<int64_t>(1, std::min<int64_t>(cdiv64(Tk, a2::KB), 256 / (B * H) < 1 ? 1 : 256 / (B * H)));
+  return parts * bwd_ws_part_floats(B, H, Tq, dh) * (int64_t)sizeof(float);
 }
 
 bool neurst_mha2_bwd_eligible(const Mha2Problem& p, int64_t ws_bytes) {
@@ -911,8 +962,17 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
                                       : (w8 ? a2::mha2_bwd_kernel<64, false, false, 8> : a2::mha2_bwd_kernel<64, false, false, 4>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) { neurst_set_error("mha2_bwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
-  kern<<<dim3((unsigned)(p.B * p.H)), w8 ? 512 : 256, smem, s>>>(a);
+  a.ksplit = (int)bwd_ksplit(p.B, p.H, p.Tk);
+  a.ws_part = bwd_ws_part_floats(p.B, p.H, p.Tq, p.dh);
+  kern<<<dim3((unsigned)(p.B * p.H * a.ksplit)), w8 ? 512 : 256, smem, s>>>(a);
   NEURST_CHECK_LAUNCH("mha2_bwd");
+  if (a.ksplit > 1) {
+    const int64_t units = p.B * p.H * p.Tq * (p.dh / 4);
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(units, 256 * 4), 2048);
+    if (p.dh == 96) a2::mha2_dq_reduce_kernel<96><<<grid, 256, 0, s>>>(a);
+    else a2::mha2_dq_reduce_kernel<64><<<grid, 256, 0, s>>>(a);
+    NEURST_CHECK_LAUNCH("mha2_dq_reduce");
+  }
   return NEURST_OK;
 }
 
@@ -954,7 +1014,11 @@ int neurst_mha2_fwd_launch(const Mha2FwdProblem& p, hipStream_t s) {
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) { neurst_set_error("mha2_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
-  kern<<<dim3((unsigned)(p.B * p.H)), 512, smem, s>>>(a);
+  // Fewer (batch, head) pairs than CUs (batch 16 at eight heads: 128): the groups of eight query slices of a pair go to several
+  // workgroups, each sweeping all keys for its own groups (K / V are read once more per part; the pairs' parts share an L2).
+  const int64_t ngroup = cdiv64(cdiv64(p.Tq, a2::QS), a2::FW), per_chip = (g_opt_mha_split & 1) ? 256 / (p.B * p.H) : 1;
+  a.qsplit = (int)(per_chip < 1 ? 1 : (per_chip > ngroup ? ngroup : per_chip));
+  kern<<<dim3((unsigned)(p.B * p.H * a.qsplit)), 512, smem, s>>>(a);
   NEURST_CHECK_LAUNCH("mha2_fwd");
   return NEURST_OK;
 }

@@ -638,6 +638,45 @@ def test_attention_fused_backward(B, H, Tq, Tk, mode, rate, dh):
         assert relerr(got[live], two[live]) < 2e-2, name   # both paths round the same quantities to bf16 at different places
 
 
+@pytest.mark.parametrize('B,H,Tq,Tk,dh,rate', [(16, 8, 500, 500, 96, 0.1), (17, 7, 300, 530, 64, 0.1), (10, 8, 530, 700, 96, 0.0), (32, 4, 257, 300, 96, 0.1)])
+def test_attention_work_of_a_pair_split_over_workgroups(B, H, Tq, Tk, dh, rate):
+    """Fewer (batch, head) pairs than CUs (batch 16 at eight heads): the fused forward hands the groups of eight query slices of
+    a pair to several workgroups, the fused backward its key blocks, with dQ summed from fp32 slices by a second launch
+    (neurst_set_option mha_split: bit 1 forward, bit 2 backward).  Against one workgroup per pair on the same inputs: O, lse, dK
+    and dV bit-identical (the same code computes every element), dQ bit-identical when a part owns one key block (the same
+    two or three fp32 addends in the same order) and to one bf16 rounding otherwise.  Ragged lengths: pairs with a single
+    valid key block write dQ themselves, parts without a block do nothing."""
+    rng = np.random.default_rng(B + Tq)
+    d = H * dh
+    mk = lambda *s: dev(bf16_round(rng.standard_normal(s) * 0.7), torch.bfloat16)
+    q, k, v, do = mk(B, Tq, d), mk(B, Tk, d), mk(B, Tk, d), mk(B, Tq, d)
+    lens = rng.integers(1, Tk + 1, size=B).astype(np.int32)
+    lens[0], lens[1] = Tk, min(Tk, 200)
+    ld = dev(lens)
+    key = O.site_key(4, 55, 1)
+    res = {}
+    try:
+        for split in (0, 3):
+            ops.set_option('mha_split', split)
+            ops.set_option('mha_fused', 2)
+            r = ops.mha_fwd(q, k, v, d, d, d, B, H, Tq, Tk, dh, O.MASK_KEYPAD, ld, rate, key, keep_bits=rate > 0)
+            o, lse, kb = (tuple(r) + (None,))[:3]
+            dq, dk, dv = (torch.full_like(x, float('nan')) for x in (q, k, v))
+            ops.mha_bwd(q, k, v, o, do, lse, dq, dk, dv, d, d, d, d, d, d, B, H, Tq, Tk, dh, O.MASK_KEYPAD, ld, rate, key, keep_bits=kb)
+            res[split] = [host(t) for t in (o, lse, dk, dv, dq)]
+    finally:
+        ops.set_option('mha_split', 3)
+        ops.set_option('mha_fused', 1)
+    for name, a_, b_ in zip(('o', 'lse', 'dk', 'dv'), res[0], res[3]):
+        assert np.array_equal(a_, b_), name
+    assert np.isfinite(res[3][4]).all()
+    nkb, parts = -(-Tk // 256), min(-(-Tk // 256), max(256 // (B * H), 1))
+    if parts == nkb:
+        assert np.array_equal(res[0][4], res[3][4])
+    else:
+        assert relerr(res[3][4], res[0][4]) < 1e-2
+
+
 def test_attention_packed_qkv_strides():
     rng = np.random.default_rng(11)
     B, H, T, dh = 2, 2, 50, 16
