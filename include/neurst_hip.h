@@ -46,7 +46,9 @@ int neurst_abi_version(void);
  * launches use at most n workgroups (a launch beside a latency-bound chain on another stream leaves that chain CUs), 0 = all; "mha_fused" 0 / 1 / 2 = the wide
  * attention forward and the one-kernel backward of attention2.hip never / for encoder-size shapes / whenever they can
  * take the shape (bf16, dh = 96 or 64, no causal mask); "mha_small_fused" 1/0 = dQ and dK / dV of short-query shapes
- * (Tq <= 256) in one launch; "mha_bwd_waves" 4 / 8 = waves per workgroup of the one-kernel backward; "conv_fast" 1/0 =
+ * (Tq <= 256) in one launch; "mha_bwd_waves" 4 / 8 = waves per workgroup of the one-kernel backward; "mha_split" bits (default 3):
+ * with fewer (batch, head) pairs than CUs, 1 = the wide forward hands a pair's query groups to several workgroups, 2 = the
+ * one-kernel backward its key blocks (dQ summed by a second launch); "conv_fast" 1/0 =
  * bf16 fast paths of the conv front end; "ln_prefetch" bits (default 53): 16 / 32 = LayerNorm forward / backward of bf16 rows of
  * 768, 512 or 256 columns without a row mask through the straight-line kernels, 1 / 2 = the general forward / backward row
  * loops request the next row ahead of the current row's stores, 4 / 8 = they take 8-byte lanes where a row is whole wave
