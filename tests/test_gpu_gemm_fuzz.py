@@ -7,11 +7,14 @@ output type / padded leading dimensions independently, so the combinations the s
 ldc on the straight-line epilogues, ...) are compared with fp64 numpy as well.  `dense`, /root/reference/st/models/tools/utils.py:367-398.
 Tolerances: fp32 output of bf16 operands 1e-5 of the result's maximum (fp32 accumulation against fp64), bf16 output 1e-2
 (one bf16 rounding of the result, 2^-8, on top)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+FUZZ_SCALE = int(os.environ.get('NEURST_FUZZ_SCALE', '1'))     # more seeds for a longer hunt (not the committed suite)
 
 if torch.cuda.is_available():
     from neurst_amd import ops
@@ -56,7 +59,7 @@ BUCKETS = ['staged', 'thin32', 'thin64', 'small4', 'mid', 'persist', 'long256', 
 
 
 @pytest.mark.parametrize('bucket', BUCKETS)
-@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('seed', range(6 * FUZZ_SCALE))
 def test_gemm_dispatch_random_flags(bucket, seed):
     rng = np.random.default_rng(7919 * seed + BUCKETS.index(bucket))
     M, N, K, ta, tb, aligned = _draw_shape(rng, bucket, seed)

@@ -6,6 +6,8 @@ decisions from the same hash) are drawn independently.  fp32 parity mode, the no
 dropout), every gradient tensor 1e-4 of its largest entry (floor 1e-3 on tensors whose exact gradient is zero: one visible key)."""
 import copy
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,7 @@ from oracle.model import OracleTPE
 from neurst_amd.synthetic import make_batch
 
 pytestmark = pytest.mark.gpu
+FUZZ_SCALE = int(os.environ.get('NEURST_FUZZ_SCALE', '1'))     # more seeds for a longer hunt (not the committed suite)
 
 
 def _args(rng, case, dropout):
@@ -49,7 +52,7 @@ def _args(rng, case, dropout):
     return build_args(copy.deepcopy(cfg), dim_output=V, compute_dtype='fp32'), d, V
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(16 * FUZZ_SCALE))
 def test_fp32_train_step_random_configs_match_oracle(seed, monkeypatch):
     from neurst_amd.st.models.TransformerTPE import GlobalStep
     if seed % 4 == 3:
@@ -100,7 +103,7 @@ def test_fp32_train_step_random_configs_match_oracle(seed, monkeypatch):
         assert err < 1e-4, (k, err, what)
 
 
-@pytest.mark.parametrize('seed', range(10))
+@pytest.mark.parametrize('seed', range(10 * FUZZ_SCALE))
 def test_fp32_greedy_decoding_random_configs_bit_exact(seed):
     """cached greedy decoding (TransformerTPE.py:366-484, transformer_decoder.py:184-246) of random configurations: token ids,
     CTC predictions and decoded lengths equal the oracle's bit for bit in fp32 mode"""

@@ -6,6 +6,8 @@ st/models/tools/blocks.py:8-38, smoothing_cross_entropy st/layers/common_layers_
 The fixed cases of test_gpu_ops.py pin the degenerate inputs; here widths, row counts, lengths (zero included), dropout rates
 and dtypes are drawn independently so that every dispatch path (straight-line / 16-byte / 8-byte / scalar LayerNorm lanes,
 register-resident / streaming CTC rows, one- and multi-wave label counts) sees shapes nobody wrote down."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -13,6 +15,7 @@ import torch
 from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
+FUZZ_SCALE = int(os.environ.get('NEURST_FUZZ_SCALE', '1'))     # more seeds for a longer hunt (not the committed suite)
 
 if torch.cuda.is_available():
     from neurst_amd import ops
@@ -36,7 +39,7 @@ def _relerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
-@pytest.mark.parametrize('seed', range(36))
+@pytest.mark.parametrize('seed', range(36 * FUZZ_SCALE))
 def test_residual_layernorm_random_shapes(seed):
     rng = np.random.default_rng(5100 + seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
@@ -69,7 +72,7 @@ def test_residual_layernorm_random_shapes(seed):
         assert _relerr(_host(got), want) < tol, (name, _relerr(_host(got), want), what)
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(24 * FUZZ_SCALE))
 def test_ctc_random_batches(seed):
     """loss, gradient (fp32, scaled, in place, bf16) and the greedy path of random batches: repeated labels, utterances shorter
     than their label sequence (ignored: loss 0, gradient 0), label counts on both sides of one wavefront's 2U + 1 <= 64 states"""
@@ -110,7 +113,7 @@ def test_ctc_random_batches(seed):
     assert np.abs(_host(g3) - scale * ref_grad).max() <= 1e-2 * max(np.abs(ref_grad).max() * scale, 1e-12) + 1e-30, what
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(16 * FUZZ_SCALE))
 def test_ls_xent_random_batches(seed):
     rng = np.random.default_rng(8800 + seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
@@ -129,7 +132,7 @@ def test_ls_xent_random_batches(seed):
     assert _relerr(_host(grad), scale * ref_grad) < 1e-5, what
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(16 * FUZZ_SCALE))
 def test_shrink_random_batches(seed):
     """frames whose greedy CTC label is blank or repeats its predecessor are dropped (blocks.py:8-38): index, new lengths,
     gathered rows and their scatter back are bit-exact, for blank-heavy and label-heavy logits, zero-length utterances included"""
