@@ -925,7 +925,8 @@ bool neurst_mha2_bwd_eligible(const Mha2Problem& p, int64_t ws_bytes) {
   // one workgroup per (batch, head): below ~half a chip of them (single-utterance inference) the tiled kernels of
   // attention.hip, ceil(T / 64) workgroups per (batch, head), fill the CUs better
   // (short queries over long keys - the decoder's cross attention, Tq = 40 over Tk = 500 - stay here: 28 against 51 us per launch)
-  if (g_opt_mha_fused == 1 && (p.Tk < 128 || p.B * p.H < 128)) return false;
+  // (with the key blocks of a pair on several workgroups the count that matters is workgroups: batch 8 = 64 pairs x 2 blocks)
+  if (g_opt_mha_fused == 1 && (p.Tk < 128 || p.B * p.H * bwd_ksplit(p.B, p.H, p.Tk) < 128)) return false;
   if (ws_bytes < neurst_mha_bwd_workspace_bytes(p.B, p.H, p.Tq, p.Tk, p.dh)) return false;
   auto al16 = [](const void* x, int64_t ld) { return ((uintptr_t)x & 15) == 0 && (ld * 2) % 16 == 0; };
   if (!al16(p.q, p.ldq) || !al16(p.k, p.ldk) || !al16(p.v, p.ldv) || !al16(p.o, p.ldo) || !al16(p.d_o, p.ldo)) return false;
@@ -977,11 +978,18 @@ int neurst_mha2_bwd_launch(const Mha2Problem& p, float* ws, hipStream_t s) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
+// workgroups per (batch, head) of the wide forward: with fewer pairs than CUs (batch 16 at eight heads: 128) the groups of eight
+// query slices of a pair go to several workgroups, each sweeping all keys for its own groups (K / V are read once more per
+// part; the parts of a pair share an L2)
+static int64_t fwd_qsplit(int64_t B, int64_t H, int64_t Tq) {
+  const int64_t ngroup = cdiv64(cdiv64(Tq, a2::QS), a2::FW), per_chip = (g_opt_mha_split & 1) ? 256 / (B * H) : 1;
+  return per_chip < 1 ? 1 : (per_chip > ngroup ? ngroup : per_chip);
+}
 bool neurst_mha2_fwd_eligible(const Mha2FwdProblem& p) {
   if (!g_opt_mha_fused || p.dtype != NEURST_BF16 || (p.dh != 96 && p.dh != 64)) return false;
   if (p.mask_mode == NEURST_MASK_CAUSAL) return false;
   if (p.B * p.H > 65535 * 16) return false;
-  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128 || p.B * p.H < 128)) return false;   // as the backward
+  if (g_opt_mha_fused == 1 && (p.Tq < 128 || p.Tk < 128 || p.B * p.H * fwd_qsplit(p.B, p.H, p.Tq) < 128)) return false;   // as the backward
   auto al16 = [](const void* x, int64_t ld) { return ((uintptr_t)x & 15) == 0 && (ld * 2) % 16 == 0; };
   if (!al16(p.q, p.ldq) || !al16(p.k, p.ldk) || !al16(p.v, p.ldv) || !al16(p.o, p.ldo)) return false;
   if ((p.bsq * 2) % 16 || (p.bsk * 2) % 16 || (p.bsv * 2) % 16 || (p.bso * 2) % 16) return false;
@@ -1014,10 +1022,7 @@ int neurst_mha2_fwd_launch(const Mha2FwdProblem& p, hipStream_t s) {
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) { neurst_set_error("mha2_fwd: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e)); return NEURST_E_LAUNCH; }
-  // Fewer (batch, head) pairs than CUs (batch 16 at eight heads: 128): the groups of eight query slices of a pair go to several
-  // workgroups, each sweeping all keys for its own groups (K / V are read once more per part; the pairs' parts share an L2).
-  const int64_t ngroup = cdiv64(cdiv64(p.Tq, a2::QS), a2::FW), per_chip = (g_opt_mha_split & 1) ? 256 / (p.B * p.H) : 1;
-  a.qsplit = (int)(per_chip < 1 ? 1 : (per_chip > ngroup ? ngroup : per_chip));
+  a.qsplit = (int)fwd_qsplit(p.B, p.H, p.Tq);
   kern<<<dim3((unsigned)(p.B * p.H * a.qsplit)), 512, smem, s>>>(a);
   NEURST_CHECK_LAUNCH("mha2_fwd");
   return NEURST_OK;
